@@ -1,0 +1,203 @@
+/* exa_hip.h — C ABI of the MI355X-native ExaBrick render module (libexa_hip.so).
+ *
+ * This is the drop-in boundary for the reference's `exa::OptixRenderer`
+ * (exa/OptixRenderer.h:32-97) and the device programs it launches
+ * (programs/exabrick.cu).  Plain pointers and sizes only; no C++/torch types.
+ * The C++ facade `exa::Renderer` (owlexabrick_amd/host/Renderer.h) keeps the
+ * OptixRenderer method names on top of these entry points; INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Two groups:
+ *   exa_prep_*  host-side data preparation the OptixRenderer constructor does
+ *               (brick flattening, scalar gather, same-bricks regions)
+ *   exa_hip_*   the device module (upload, LBVH, activity, render, readback)
+ *
+ * All functions return 0 on success, non-zero on error; the message is
+ * available from exa_hip_last_error()/exa_prep_last_error().  Nothing here
+ * falls back to a CPU renderer: without a HIP device exa_hip_create fails.
+ */
+#ifndef EXA_HIP_H
+#define EXA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EXA_NUM_XF_VALUES      128 /* exa/common.h:41 */
+#define EXA_MAX_CHANNELS       10  /* exa/common.h:42 */
+#define EXA_MAX_ISO_SURFACES   2   /* exa/common.h:43 */
+#define EXA_MAX_CONTOUR_PLANES 3   /* exa/common.h:44 */
+
+/* ---- POD mirrors of the reference's shared host/device structs ---- */
+
+/* programs/Brick.h:31-71 */
+typedef struct ExaBrick {
+  int32_t  lower[3];
+  int32_t  size[3];
+  int32_t  level;
+  uint32_t begin;   /* offset of the brick's first cell in the gathered scalar arrays */
+} ExaBrick;
+
+/* exa/Regions.h:31-41 (ExaBrickRegions::BrickRegion == SameBricksRegion) */
+typedef struct ExaBrickRegion {
+  float   domain_lo[3], domain_hi[3];
+  float   valueRange_lo, valueRange_hi;
+  int32_t leafListBegin;
+  int32_t leafListSize;
+  float   finestLevelCellWidth;
+} ExaBrickRegion;
+
+/* programs/FrameState.h:29-71.  The per-channel cudaTextureObject_t handles are
+ * replaced by exa_hip_set_xf(); bools are int32. */
+typedef struct ExaHipFrameState {
+  float cam_pos[3], cam_dir00[3], cam_dirDu[3], cam_dirDv[3];
+  struct { int32_t enabled; float value; int32_t channel; } iso[EXA_MAX_ISO_SURFACES];
+  struct { int32_t enabled; float normal[3]; int32_t channel; float offset; } contour[EXA_MAX_CONTOUR_PLANES];
+  struct { float lo[3], hi[3]; int32_t enabled; } clipBox;
+  struct { float length; int32_t enabled; } ao;
+  float   clockScale;
+  float   xfm_vx[3], xfm_vy[3], xfm_vz[3], xfm_p[3]; /* affine3f voxelSpaceTransform */
+  int32_t frameID;
+  float   xfDomain[EXA_MAX_CHANNELS][2];
+  float   xfOpacityScale;
+} ExaHipFrameState;
+
+/* the scalar launch parameters of programs/LaunchParams.h:26-80 the path reads,
+ * plus VolumeData.numChannels / spaceSkippingEnabled (programs/VolumeData.h:24-31) */
+typedef struct ExaHipParams {
+  float   dt;                   /* OptixRenderer::updateDt            (OptixRenderer.cpp:413-416) */
+  int32_t numPrimaryChannels;   /* multiFieldDvr ? #fields : 1        (OptixRenderer.cpp:284)     */
+  int32_t colormapChannel;      /*                                    (OptixRenderer.cpp:278-283) */
+  int32_t gradientShadingDVR;   /* setGradientShadingDVR              (OptixRenderer.cpp:434-437) */
+  int32_t gradientShadingISO;   /* setGradientShadingISO              (OptixRenderer.cpp:439-442) */
+  int32_t numChannels;          /* VolumeData.numChannels             (OptixRenderer.cpp:650)     */
+  int32_t spaceSkippingEnabled; /* !contourPlanesActive && doSpaceSkipping (OptixRenderer.cpp:418-432) */
+} ExaHipParams;
+
+/* what the OptixRenderer constructor uploads (OptixRenderer.cpp:95-98,133-141,160-168) */
+typedef struct ExaHipScene {
+  const ExaBrick       *bricks;        uint64_t numBricks;
+  const ExaBrickRegion *regions;       uint64_t numRegions;
+  const int32_t        *leafList;      uint64_t leafListSize;
+  const float          *scalars;       /* numFields * totalCells floats, brick order    */
+  const uint64_t       *channelOffset; /* numFields entries (reference: 32-bit unsigned) */
+  uint64_t              totalCells;
+  int32_t               numFields;
+  float                 voxelBounds_lo[3], voxelBounds_hi[3];
+} ExaHipScene;
+
+/* work counters of one frame (instrumented kernel variant); the basis of the
+ * algorithmic-bytes figure in DESIGN.md */
+typedef struct ExaHipStats {
+  uint64_t segments;      /* traceVolumeRay hits                                  */
+  uint64_t sample_evals;  /* samplePoint[WithDerivative] calls in the DVR march    */
+  uint64_t samples;       /* ...of which valid                                     */
+  uint64_t brick_visits;  /* addBasisFunctions calls, all paths                    */
+  uint64_t corner_loads;  /* cell scalars read, all paths                          */
+  uint64_t iso_segments;  /* iso-BVH hits                                          */
+  uint64_t iso_evals;     /* sample calls of the iso march (+ re-samples)          */
+  uint64_t nodes_visited; /* LBVH nodes fetched (64 B each), both BVHs             */
+  uint64_t pixels;        /* pixels rendered by this handle (its tile shard)       */
+  float    kernel_ms;     /* hipEvent time of the last render launch               */
+  float    rebuild_ms;    /* hipEvent time of the last activity+refit pass         */
+} ExaHipStats;
+
+typedef struct ExaHipRenderer ExaHipRenderer;
+typedef struct ExaPrep ExaPrep;
+
+/* ------------------------------------------------------------------ */
+/* host data preparation                                               */
+/* ------------------------------------------------------------------ */
+
+/* OptixRenderer::OptixRenderer data prep (exa/OptixRenderer.cpp:71-141):
+ * brick flattening with running `begin`, index-vector concat, per-field gather
+ * scalar[i] = field[cellID[i]]; then ExaBrickRegions::buildFrom
+ * (exa/Regions.cpp:242-320) over the first numRegionFields fields.
+ * bricks7 = numBricks x {size.xyz, lower.xyz, level}, the `.bricks` record
+ * header order (exa/ExaBricks.cpp:27-33).  Errors mirror the reference's
+ * std::runtime_error texts. */
+int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
+                    const int32_t *cellIDs, uint64_t numCellIDs,
+                    const float *const *fields, const uint64_t *fieldLen,
+                    int32_t numFields, int32_t numRegionFields, int32_t numThreads,
+                    ExaPrep **out);
+void exa_prep_destroy(ExaPrep *);
+/* fills an ExaHipScene whose pointers stay valid until exa_prep_destroy */
+int  exa_prep_scene(const ExaPrep *, ExaHipScene *out);
+const char *exa_prep_last_error(void);
+
+/* ------------------------------------------------------------------ */
+/* device module                                                       */
+/* ------------------------------------------------------------------ */
+
+/* replaces the upload + accel half of OptixRenderer::OptixRenderer
+ * (exa/OptixRenderer.cpp:95-98,133-141,160-168,305-316): copies the scene to HBM
+ * on `device`, builds the LBVH over the regions.  The caller's arrays are not
+ * referenced after return. */
+int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **out);
+int exa_hip_destroy(ExaHipRenderer *);
+
+/* OptixRenderer::resizeFrameBuffer (exa/OptixRenderer.cpp:341-355): (re)allocates
+ * the float4 accumulation buffer; the colour destination is passed per render. */
+int exa_hip_resize(ExaHipRenderer *, int32_t width, int32_t height);
+
+/* whole-struct upload as every OptixRenderer setter does (updateCamera,
+ * updateFrameID, updateIsoValues, setVoxelSpaceTransform ...;
+ * exa/OptixRenderer.cpp:322-339,357-368,406-411,489-502).  A change of
+ * xfDomain/xfOpacityScale marks the volume LBVH dirty, a change of iso[] marks
+ * the iso LBVH dirty (needVolumeBVHRebuild / needIsoBVHRebuild). */
+int exa_hip_set_frame_state(ExaHipRenderer *, const ExaHipFrameState *);
+
+/* OptixRenderer::updateXF texture upload (exa/OptixRenderer.cpp:385-402):
+ * 128 x (r,g,b,a) for channel `chan`; marks the volume LBVH dirty. */
+int exa_hip_set_xf(ExaHipRenderer *, int32_t chan, const float *rgba128);
+
+/* updateDt / setSpaceSkipping / setGradientShading* (exa/OptixRenderer.cpp:413-442) */
+int exa_hip_set_params(ExaHipRenderer *, const ExaHipParams *);
+
+/* image-space sharding for multi-GPU: this handle renders the 16x16-pixel tiles
+ * t with t % worldSize == rank (row-major tile order) and writes them compactly,
+ * tile-major, 256 pixels per tile.  rank 0 / worldSize 1 = whole frame in the
+ * normal row-major layout.  New relative to the reference (it never shards). */
+int exa_hip_set_shard(ExaHipRenderer *, int32_t rank, int32_t worldSize);
+/* number of uint32 pixels exa_hip_render writes for the current size/shard */
+uint64_t exa_hip_output_pixels(const ExaHipRenderer *);
+/* root side of the gather: `gathered` holds worldSize shards back to back, each
+ * padded to shardStridePixels; writes the row-major W*H image.  Device pointers. */
+int exa_hip_untile(ExaHipRenderer *, const uint32_t *gathered, uint64_t shardStridePixels,
+                   int32_t worldSize, uint32_t *rgba8_out, void *hipStream);
+
+/* OptixRenderer::render (exa/OptixRenderer.cpp:531-552): re-evaluates region
+ * activity and refits the dirty LBVH(s), then launches the frame.
+ * rgba8 is the caller-owned colour buffer (resizeFrameBuffer's fbPointer):
+ * a device pointer if dstIsDevice, else host memory (copied back synchronously).
+ * hipStream: a hipStream_t or NULL for the default stream.  Synchronous unless
+ * dstIsDevice and async != 0. */
+int exa_hip_render(ExaHipRenderer *, uint32_t *rgba8, int32_t dstIsDevice,
+                   void *hipStream, int32_t async);
+
+/* same frame through the instrumented kernel variant; fills counters */
+int exa_hip_render_stats(ExaHipRenderer *, uint32_t *rgba8, int32_t dstIsDevice, ExaHipStats *out);
+int exa_hip_get_stats(ExaHipRenderer *, ExaHipStats *out);
+
+/* accumulation buffer (float4 per pixel, row-major, this shard's layout) */
+int exa_hip_read_accum(ExaHipRenderer *, float *dst4);
+int exa_hip_write_accum(ExaHipRenderer *, const float *src4);
+
+/* region activity as the VolumeBVH / IsoSurface bounds programs see it
+ * (programs/exabrick.cu:285-312, 373-402), one byte per region; for tests */
+int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, uint8_t *dst);
+
+/* tuning knobs that never change results: "tile_order" 0 = row-major tile launch
+ * order, 1 = XCD-aware supertile order */
+int exa_hip_set_option(ExaHipRenderer *, const char *key, int32_t value);
+
+const char *exa_hip_last_error(const ExaHipRenderer * /* may be NULL: creation errors */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

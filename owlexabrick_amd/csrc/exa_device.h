@@ -1,0 +1,76 @@
+// exa_device.h — device-side data layout shared by the module (exa_module.cpp)
+// and the kernels (exa_kernels.hip).  gfx950 only.
+#pragma once
+#include "../../include/exa_hip.h"
+#include <hip/hip_runtime.h>
+
+namespace exa {
+
+// One LBVH node = 64 bytes = four 16-byte loads.  Both children's boxes live in
+// the parent, so a leaf is tested without touching its region record:
+//   q0 = (lo0.x lo0.y lo0.z hi0.x)  q1 = (hi0.y hi0.z lo1.x lo1.y)
+//   q2 = (lo1.z hi1.x hi1.y hi1.z)  c  = (child0, child1, -, -)
+// child >= 0: internal node index; child < 0: leaf, region id = ~child.
+// A child whose subtree holds no active region has lo.x > hi.x (refit writes
+// lo = +FLT_MAX, hi = -FLT_MAX) and is skipped.
+struct alignas(64) BvhNode {
+  float4 q0, q1, q2;
+  int32_t child0, child1, pad0, pad1;
+};
+static_assert(sizeof(BvhNode) == 64, "node must be one 64-byte line");
+
+// what the march needs from a region (16 B, one load per segment); the box comes
+// from the LBVH node, the value range is only needed by the activity kernel.
+struct alignas(16) RegionInfo {
+  int32_t listBegin;      // offset into leafList
+  int32_t listSize;       // k = number of bricks overlapping in this region
+  float   finestLevelCellWidth;
+  int32_t firstBrick;     // leafList[listBegin], saves a dependent load
+};
+
+struct DeviceScene {
+  const int4       *bricks;        // ExaBrick as two int4: (lower.xyz,size.x) (size.yz,level,begin)
+  const int32_t    *leafList;
+  const float      *scalars;
+  const RegionInfo *regionInfo;
+  const float2     *valueRange;    // per region
+  const float      *domain;        // per region 6 floats (lo, hi) for refit
+  unsigned long long channelOffset[EXA_MAX_CHANNELS];
+  uint32_t numRegions;
+  uint32_t numInternal;            // internal LBVH nodes
+};
+
+enum { kTile = 16, kTilePixels = 256, kStackDepth = 32 };
+
+enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CORNER_LOADS,
+                ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES, ST_COUNT };
+
+struct RenderArgs {
+  DeviceScene        sc;
+  const BvhNode     *volNodes;
+  const BvhNode     *isoNodes;
+  ExaHipFrameState   fs;
+  ExaHipParams       p;
+  const float4      *xf;            // numXfChannels x 128 (r,g,b,a)
+  int32_t            numXfChannels;
+  int32_t            W, H, tilesX, tilesY;
+  int32_t            rank, world;   // image-space shard
+  const int32_t     *tileMap;       // blockIdx.x -> global tile id (launch order)
+  uint32_t          *color;
+  float4            *accum;
+  unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
+  int32_t           *errorFlag;     // set when a loop guard trips
+};
+
+// ---- launchers implemented in exa_kernels.hip ----
+hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s);
+hipError_t launchVolumeActivity(const DeviceScene &sc, const ExaHipFrameState &fs, const ExaHipParams &p,
+                                const float4 *xf, uint8_t *active, hipStream_t s);
+hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, uint8_t *active, hipStream_t s);
+// refit one height class of internal nodes: box of each child = union below it
+hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
+                       const uint8_t *active, hipStream_t s);
+hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,
+                        int W, int H, uint32_t *out, hipStream_t s);
+
+} // namespace exa

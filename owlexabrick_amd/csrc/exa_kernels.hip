@@ -1,0 +1,781 @@
+// exa_kernels.hip — hand-written HIP kernels for gfx950 (MI355X, wave64).
+//
+// One thread per pixel, one wave per 8x8 pixel block, one 256-thread workgroup
+// per 16x16 tile.  Replaces the OptiX raygen program `renderFrame` and the
+// VolumeBVH / IsoSurface bounds+intersect programs of programs/exabrick.cu.
+// Arithmetic order follows the reference expression by expression (cited per
+// function); the file is built with -ffp-contract=off so results can be
+// compared against the CPU oracle operation for operation.
+#include "exa_device.h"
+#include <cfloat>
+
+namespace exa {
+
+// ------------------------------------------------------------------------
+// small vector helpers (owl::vec3f semantics: componentwise, left-to-right dot)
+// ------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 mk(const float *p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalize(V3 a) { return (1.f / sqrtf(dot(a, a))) * a; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{ return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+// owl xfmPoint / xfmVector (embree-style madd chains)
+__device__ __forceinline__ V3 xfmPoint(const ExaHipFrameState &fs, V3 p)
+{ return p.x * mk(fs.xfm_vx) + (p.y * mk(fs.xfm_vy) + (p.z * mk(fs.xfm_vz) + mk(fs.xfm_p))); }
+__device__ __forceinline__ V3 xfmVector(const ExaHipFrameState &fs, V3 v)
+{ return v.x * mk(fs.xfm_vx) + (v.y * mk(fs.xfm_vy) + v.z * mk(fs.xfm_vz)); }
+
+// owl::common::LCG<16>
+struct Lcg {
+  uint32_t state;
+  __device__ __forceinline__ void init(uint32_t v0, uint32_t v1)
+  {
+    uint32_t s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 16; n++) {
+      s0 += 0x9e3779b9u;
+      v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+      v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    state = v0;
+  }
+  __device__ __forceinline__ float next()
+  {
+    state = 1664525u * state + 1013904223u;
+    return float(state & 0x00FFFFFFu) / float(0x01000000);
+  }
+};
+
+struct Ray { V3 org, dir; float tmin, tmax; };
+struct Color4 { float x, y, z, w; };
+
+// per-thread view of the kernel state
+template <bool STATS>
+struct Ctx {
+  const RenderArgs *a;
+  const float4 *xfLds;         // TF tables staged in LDS
+  int *stack;                  // this thread's LBVH stack column in LDS (stride 256)
+  unsigned long long st[ST_COUNT];
+  bool guardTripped;
+  __device__ __forceinline__ void count(int slot, unsigned long long n = 1) { if (STATS) st[slot] += n; }
+};
+
+// ------------------------------------------------------------------------
+// exabrick.cu:53-76  sRGB + 8-bit pack
+// ------------------------------------------------------------------------
+__device__ __forceinline__ float linear_to_srgb(float x)
+{
+  if (x <= 0.0031308f) return 12.92f * x;
+  return 1.055f * powf(x, 1.f / 2.4f) - 0.055f;
+}
+__device__ __forceinline__ uint32_t make_8bit(float f) { return (uint32_t)min(255, max(0, int(f * 256.f))); }
+__device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b)
+{ return (make_8bit(r) << 0) + (make_8bit(g) << 8) + (make_8bit(b) << 16) + (0xffu << 24); }
+
+// ------------------------------------------------------------------------
+// exabrick.cu:135-150 lookupTransferFunction; the tex1D<float4> fetch
+// (128 texels, linear, clamp, normalized coords) is a software lerp on the
+// LDS-resident table: x = u*128-0.5, T[i]*(1-a) + T[i+1]*a.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameState &fs, float in_scalar, int channel)
+{
+  const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
+  float scalar = (EXA_NUM_XF_VALUES - 1) * (in_scalar - lo) / ((hi - lo) + 1e-20f);
+  scalar = fminf(EXA_NUM_XF_VALUES - 1.f, fmaxf(0.f, scalar + .5f));
+  scalar /= EXA_NUM_XF_VALUES - 1.f;
+  const float x = scalar * float(EXA_NUM_XF_VALUES) - 0.5f;
+  const float fl = floorf(x);
+  const float al = x - fl;
+  const int i0 = min(EXA_NUM_XF_VALUES - 1, max(0, int(fl)));
+  const int i1 = min(EXA_NUM_XF_VALUES - 1, max(0, int(fl) + 1));
+  const float4 T0 = xf[channel * EXA_NUM_XF_VALUES + i0];
+  const float4 T1 = xf[channel * EXA_NUM_XF_VALUES + i1];
+  const float na = 1.f - al;
+  Color4 r;
+  r.x = na * T0.x + al * T1.x;
+  r.y = na * T0.y + al * T1.y;
+  r.z = na * T0.z + al * T1.z;
+  r.w = na * T0.w + al * T1.w;
+  r.w *= fs.xfOpacityScale;
+  return r;
+}
+
+// ------------------------------------------------------------------------
+// exabrick.cu:197-210 boxTest (true division, NaN-ignoring min/max)
+// ------------------------------------------------------------------------
+__device__ __forceinline__ bool boxTest(const Ray &ray, V3 lo, V3 hi, float &t0, float &t1)
+{
+  const float lx = (lo.x - ray.org.x) / ray.dir.x, hx = (hi.x - ray.org.x) / ray.dir.x;
+  const float ly = (lo.y - ray.org.y) / ray.dir.y, hy = (hi.y - ray.org.y) / ray.dir.y;
+  const float lz = (lo.z - ray.org.z) / ray.dir.z, hz = (hi.z - ray.org.z) / ray.dir.z;
+  const float nx = fminf(lx, hx), ny = fminf(ly, hy), nz = fminf(lz, hz);
+  const float fx = fmaxf(lx, hx), fy = fmaxf(ly, hy), fz = fmaxf(lz, hz);
+  t0 = fmaxf(ray.tmin, fmaxf(fmaxf(nx, ny), nz));
+  t1 = fminf(ray.tmax, fminf(fminf(fx, fy), fz));
+  return t0 < t1;
+}
+
+// ------------------------------------------------------------------------
+// Closest active region along the ray: the OptiX trace + VolumeBVH/IsoSurface
+// intersect program (exabrick.cu:184-238, 346-371) as a software LBVH walk.
+// Result = region with the smallest clamped entry t0 (t0 < t1); equal t0 ->
+// lowest region id; t1 clamped to the ray's own tmax only.
+// ------------------------------------------------------------------------
+struct RegionHit { int leafID; float t0, t1; };
+
+template <bool STATS>
+__device__ __forceinline__ RegionHit traceRegion(Ctx<STATS> &C, const BvhNode *nodes, const Ray &ray)
+{
+  RegionHit best; best.leafID = -1; best.t0 = INFINITY; best.t1 = 0.f;
+  int *stack = C.stack;
+  int sp = 0;
+  int node = 0;
+  for (;;) {
+    const float4 *np = reinterpret_cast<const float4 *>(nodes + node);
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    const int4 cc = *reinterpret_cast<const int4 *>(np + 3);
+    C.count(ST_NODES);
+    float a0, a1, b0, b1;
+    bool ha = boxTest(ray, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), a0, a1) && (q0.x <= q0.w);
+    bool hb = boxTest(ray, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), b0, b1) && (q1.z <= q2.y);
+    if (ha && cc.x < 0) {
+      const int id = ~cc.x;
+      if (a0 < best.t0 || (a0 == best.t0 && id < best.leafID)) { best.leafID = id; best.t0 = a0; best.t1 = a1; }
+      ha = false;
+    }
+    if (hb && cc.y < 0) {
+      const int id = ~cc.y;
+      if (b0 < best.t0 || (b0 == best.t0 && id < best.leafID)) { best.leafID = id; best.t0 = b0; best.t1 = b1; }
+      hb = false;
+    }
+    ha = ha && (a0 <= best.t0);
+    hb = hb && (b0 <= best.t0);
+    if (ha && hb) {
+      const bool aFirst = a0 <= b0;
+      stack[sp * 256] = aFirst ? cc.y : cc.x;
+      sp++;
+      node = aFirst ? cc.x : cc.y;
+    } else if (ha) {
+      node = cc.x;
+    } else if (hb) {
+      node = cc.y;
+    } else {
+      if (sp == 0) break;
+      sp--;
+      node = stack[sp * 256];
+    }
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------------
+// exabrick.cu:620-777 addBasisFunctions<NEED_DERIVATIVE>: hat-basis of one brick.
+// Branch-free: every corner's address is clamped into the brick and the
+// accumulation is selected on the reference's in-brick predicate, so the sums
+// see exactly the reference's sequence of additions.
+// ------------------------------------------------------------------------
+struct Basis { float sumWV, sumW; V3 sumD, sumDC; };
+
+template <bool DERIV, bool STATS>
+__device__ __forceinline__ void addBasisFunctions(Ctx<STATS> &C, Basis &B, const int4 b0, const int4 b1,
+                                                  const float *__restrict__ field, V3 pos)
+{
+  // b0 = (lower.xyz, size.x)  b1 = (size.y, size.z, level, begin)
+  const int sx = b0.w, sy = b1.x, sz = b1.y;
+  const float invCw = __int_as_float((127 - b1.z) << 23);   // exact 2^-level: (p/cw) == p*invCw
+  const float lpx = (pos.x - float(b0.x)) * invCw - 0.5f;
+  const float lpy = (pos.y - float(b0.y)) * invCw - 0.5f;
+  const float lpz = (pos.z - float(b0.z)) * invCw - 0.5f;
+  const int lx = max(-1, int(floorf(lpx))), ly = max(-1, int(floorf(lpy))), lz = max(-1, int(floorf(lpz)));
+  const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
+  const float fx = lpx - float(lx), fy = lpy - float(ly), fz = lpz - float(lz);
+  const float nx = 1.f - fx, ny = 1.f - fy, nz = 1.f - fz;
+  const bool vlx = lx >= 0 && lx < sx, vhx = hx < sx;
+  const bool vly = ly >= 0 && ly < sy, vhy = hy < sy;
+  const bool vlz = lz >= 0 && lz < sz, vhz = hz < sz;
+  // clamped (always in-brick) cell coordinates for the speculative loads
+  const int cxl = min(max(lx, 0), sx - 1), cxh = min(hx, sx - 1);
+  const int cyl = min(max(ly, 0), sy - 1), cyh = min(hy, sy - 1);
+  const int czl = min(max(lz, 0), sz - 1), czh = min(hz, sz - 1);
+  const uint32_t base = (uint32_t)b1.w;
+  const uint32_t rowLL = base + (uint32_t)(cyl * sx + czl * sx * sy);
+  const uint32_t rowHL = base + (uint32_t)(cyh * sx + czl * sx * sy);
+  const uint32_t rowLH = base + (uint32_t)(cyl * sx + czh * sx * sy);
+  const uint32_t rowHH = base + (uint32_t)(cyh * sx + czh * sx * sy);
+  const float s000 = field[rowLL + cxl], s100 = field[rowLL + cxh];
+  const float s010 = field[rowHL + cxl], s110 = field[rowHL + cxh];
+  const float s001 = field[rowLH + cxl], s101 = field[rowLH + cxh];
+  const float s011 = field[rowHH + cxl], s111 = field[rowHH + cxh];
+  C.count(ST_BRICK_VISITS);
+#define EXA_CORNER(VALID, S, WZ, WY, WX, SGX, SGY, SGZ)                                     \
+  {                                                                                          \
+    const bool v_ = (VALID);                                                                 \
+    const float w_ = (WZ) * (WY) * (WX);                                                     \
+    if (DERIV) {                                                                             \
+      const float dx_ = (WZ) * (WY) * (SGX 1.f);                                             \
+      const float dy_ = (WZ) * (WX) * (SGY 1.f);                                             \
+      const float dz_ = (WY) * (WX) * (SGZ 1.f);                                             \
+      B.sumDC.x = v_ ? B.sumDC.x + dx_ : B.sumDC.x;                                          \
+      B.sumDC.y = v_ ? B.sumDC.y + dy_ : B.sumDC.y;                                          \
+      B.sumDC.z = v_ ? B.sumDC.z + dz_ : B.sumDC.z;                                          \
+      B.sumD.x = v_ ? B.sumD.x + dx_ * (S) : B.sumD.x;                                       \
+      B.sumD.y = v_ ? B.sumD.y + dy_ * (S) : B.sumD.y;                                       \
+      B.sumD.z = v_ ? B.sumD.z + dz_ * (S) : B.sumD.z;                                       \
+    }                                                                                        \
+    B.sumW = v_ ? B.sumW + w_ : B.sumW;                                                      \
+    B.sumWV = v_ ? B.sumWV + w_ * (S) : B.sumWV;                                             \
+    if (STATS && v_) C.st[ST_CORNER_LOADS]++;                                                \
+  }
+  // corner order of the reference: z-lo{y-lo{x-lo,x-hi}, y-hi{..}}, z-hi{..}
+  EXA_CORNER(vlz && vly && vlx, s000, nz, ny, nx, -, -, -)   // :644-658
+  EXA_CORNER(vlz && vly && vhx, s100, nz, ny, fx, +, -, -)   // :659-673
+  EXA_CORNER(vlz && vhy && vlx, s010, nz, fy, nx, -, +, -)   // :676-691
+  EXA_CORNER(vlz && vhy && vhx, s110, nz, fy, fx, +, +, -)   // :692-706
+  EXA_CORNER(vhz && vly && vlx, s001, fz, ny, nx, -, -, +)   // :712-726
+  EXA_CORNER(vhz && vly && vhx, s101, fz, ny, fx, +, -, +)   // :727-741
+  EXA_CORNER(vhz && vhy && vlx, s011, fz, fy, nx, -, +, +)   // :744-758
+  EXA_CORNER(vhz && vhy && vhx, s111, fz, fy, fx, +, +, +)   // :759-774
+#undef EXA_CORNER
+}
+
+// exabrick.cu:781-806 samplePoint / :883-928 samplePointWithDerivative
+template <bool DERIV, bool STATS>
+__device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &derivatives,
+                                            const RegionInfo &ri, V3 pos, int channel)
+{
+  const DeviceScene &sc = C.a->sc;
+  const float *field = sc.scalars + sc.channelOffset[channel];
+  Basis B;
+  B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+  int brickID = ri.firstBrick;
+  for (int child = 0;;) {
+    const int4 b0 = sc.bricks[2 * brickID], b1 = sc.bricks[2 * brickID + 1];
+    addBasisFunctions<DERIV, STATS>(C, B, b0, b1, field, pos);
+    if (++child >= ri.listSize) break;
+    brickID = sc.leafList[ri.listBegin + child];
+  }
+  if (B.sumW <= 1e-20f) return false;
+  value = B.sumWV / B.sumW;
+  if (DERIV)
+    derivatives = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
+                     B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
+                     B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
+  return true;
+}
+
+// exabrick.cu:988-1016 integrateVolume
+template <bool STATS>
+__device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
+                                                float cellValue, V3 gradient, int finestLevelCellWidth, int channel)
+{
+  if (actual_dt == 0.f) return;
+  Color4 sample = lookupXF(C.xfLds, C.a->fs, cellValue, channel);
+  if (length(gradient) > finestLevelCellWidth * 1e-6f) {
+    const V3 lightDir = -ray.dir;
+    const float scale = fabsf(dot(lightDir, gradient)) / sqrtf(dot(gradient, gradient) * dot(lightDir, lightDir));
+    sample.x *= scale; sample.y *= scale; sample.z *= scale;
+  }
+  sample.w = 1.f - powf(1.f - sample.w, actual_dt);
+  const float k = (1.f - pixelColor.w) * sample.w;
+  pixelColor.x += k * sample.x;
+  pixelColor.y += k * sample.y;
+  pixelColor.z += k * sample.z;
+  pixelColor.w += k * 1.f;
+}
+
+#define EXA_TERMINATION_THRESHOLD 0.98f
+#define EXA_MAX_STEPS (1 << 24)
+
+// exabrick.cu:1141-1144
+__device__ __forceinline__ float firstSampleT(float t0, float dt, float off)
+{
+  const int i0 = int(ceilf((t0 - dt * off) / dt));
+  float t_i = (off + i0) * dt;
+  for (int g = 0; g < 64 && (t_i - dt) >= t0; g++) t_i = t_i - dt;
+  for (int g = 0; g < 64 && t_i < t0; g++) t_i += dt;
+  return t_i;
+}
+
+// exabrick.cu:1116-1185 integrateBrick<GRADIENT_SHADING>
+template <bool GRAD, bool STATS>
+__device__ __forceinline__ void integrateBrick(Ctx<STATS> &C, Color4 &pixelColor, float off, const Ray &ray,
+                                               const RegionInfo &ri, float t0, float t1, int numChannels)
+{
+  const float dt = C.a->p.dt * ri.finestLevelCellWidth;
+  const int finestLevelCellWidth = (int)ri.finestLevelCellWidth;
+  float t_i = firstSampleT(t0, dt, off);
+  float t_last = t0;
+  for (int step = 0;; t_i += dt, step++) {
+    if (step >= EXA_MAX_STEPS) { C.guardTripped = true; break; }
+    const float t_next = fminf(t_i, t1);
+    const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
+    const float actual_dt = t_next - t_last;
+    t_last = t_next;
+    const V3 pos = ray.org + t_sample * ray.dir;
+    float cellValue = 0.f;
+    V3 grad = mk(0.f, 0.f, 0.f);
+    for (int c = 0; c < numChannels; ++c) {
+      C.count(ST_SAMPLE_EVALS);
+      if (samplePoint<GRAD, STATS>(C, cellValue, grad, ri, pos, c)) {
+        C.count(ST_SAMPLES);
+        integrateVolume(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, c);
+      }
+    }
+    if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) break;
+    if (t_next >= t1) break;
+  }
+}
+
+// ------------------------------------------------------------------------
+// implicit iso-surface path
+// ------------------------------------------------------------------------
+struct IsoResult { Color4 pixelColor; float t_hit; V3 gradient; };
+
+// exabrick.cu:1018-1114 IsoSurfaceIntegrationFunction::operator()
+template <bool STATS>
+__device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, const Ray &ray, IsoResult &result,
+                        float t_sample, float cellValueIn, const RegionInfo &ri, int channel)
+{
+  const ExaHipFrameState &fs = C.a->fs;
+  if (lastCellValue >= -1e35f) {
+    for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) {
+      const float isoV = fs.iso[i].value;
+      if (fs.iso[i].enabled && fs.iso[i].channel == channel
+          && ((lastCellValue <= isoV && cellValueIn >= isoV) || (lastCellValue >= isoV && cellValueIn <= isoV))) {
+        const float d1 = fabsf(lastCellValue - isoV);
+        const float d2 = fabsf(cellValueIn - isoV);
+        const float w1 = 1.f - d1 / (d1 + d2);
+        const float w2 = 1.f - d2 / (d1 + d2);
+        const float tavg = last_t * w1 + t_sample * w2;
+        float cellValue = 0.f;
+        V3 grad = mk(0.f, 0.f, 0.f);
+        Color4 sample; sample.x = 1.f; sample.y = 0.f; sample.z = 0.f; sample.w = 1.f;
+        const V3 isopt = ray.org + tavg * ray.dir;
+        C.count(ST_ISO_EVALS);
+        if (C.a->p.gradientShadingISO) {
+          if (samplePoint<true, STATS>(C, cellValue, grad, ri, isopt, fs.iso[i].channel)) {
+            sample = lookupXF(C.xfLds, fs, cellValue, fs.iso[i].channel);
+            grad = normalize(grad);
+            if (dot(grad, ray.dir) > 0.f) grad = -grad;
+          }
+        } else {
+          V3 unused;
+          if (samplePoint<false, STATS>(C, cellValue, unused, ri, isopt, fs.iso[i].channel))
+            sample = lookupXF(C.xfLds, fs, cellValue, fs.iso[i].channel);
+        }
+        if (C.a->p.colormapChannel != 0) {
+          cellValue = 0.f;
+          V3 unused;
+          C.count(ST_ISO_EVALS);
+          if (samplePoint<false, STATS>(C, cellValue, unused, ri, isopt, C.a->p.colormapChannel))
+            sample = lookupXF(C.xfLds, fs, cellValue, 0);
+        }
+        sample.w = 1.f;
+        if (!isfinite(grad.x) || !isfinite(grad.y) || !isfinite(grad.z)) grad = mk(0.f, 0.f, 0.f);
+        if (length(grad) > .0f) {
+          const V3 lightDir = -ray.dir;
+          const float scale = .3f + .7f * fabsf(dot(lightDir, grad)) / sqrtf(dot(grad, grad));
+          sample.x *= scale; sample.y *= scale; sample.z *= scale;
+        }
+        const float k = (1.f - result.pixelColor.w) * sample.w;
+        result.pixelColor.x += k * sample.x;
+        result.pixelColor.y += k * sample.y;
+        result.pixelColor.z += k * sample.z;
+        result.pixelColor.w += k * 1.f;
+        result.t_hit = tavg;
+        result.gradient = grad;
+      }
+    }
+  }
+  last_t = t_sample;
+  lastCellValue = cellValueIn;
+}
+
+struct SurfaceHit { int primID; float t_hit; V3 Ng; float ambient; V3 baseColor; };
+#define EXA_PRIMID_ISOSURFACE (-23)
+
+// exabrick.cu:1408-1460 traceIsoRay with isoIntegrateBrick (:1187-1256) inlined
+template <bool STATS>
+__device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
+{
+  const ExaHipFrameState &fs = C.a->fs;
+  ray.org = xfmPoint(fs, ray.org);
+  ray.dir = xfmVector(fs, ray.dir);
+  const float dt_scale = length(ray.dir);
+  ray.dir = normalize(ray.dir);
+  float alreadyIntegratedDistance = dt_scale * ray.tmin;
+  float last_t[EXA_MAX_CHANNELS], lastCellValue[EXA_MAX_CHANNELS];
+  for (int c = 0; c < EXA_MAX_CHANNELS; c++) { last_t[c] = 0.f; lastCellValue[c] = -1e36f; }
+  SurfaceHit result;
+  result.primID = -1; result.t_hit = ray.tmax; result.Ng = mk(0.f, 0.f, 0.f);
+  result.ambient = 0.f; result.baseColor = mk(0.f, 0.f, 0.f);
+  const int numChannels = C.a->p.numPrimaryChannels;
+  for (int seg = 0;; seg++) {
+    if (seg >= (1 << 22)) { C.guardTripped = true; break; }
+    ray.tmin = alreadyIntegratedDistance;
+    ray.tmax = ray.tmax * dt_scale;                       // :1434 (re-applied every iteration)
+    const RegionHit prd = traceRegion(C, C.a->isoNodes, ray);
+    if (prd.leafID < 0) break;
+    C.count(ST_ISO_SEGMENTS);
+    const RegionInfo ri = C.a->sc.regionInfo[prd.leafID];
+    IsoResult ir;
+    ir.pixelColor.x = ir.pixelColor.y = ir.pixelColor.z = ir.pixelColor.w = 0.f;
+    ir.t_hit = -1.f; ir.gradient = mk(0.f, 0.f, 0.f);
+    {
+      const float t0 = fmaxf(ray.tmin, prd.t0), t1 = fminf(ray.tmax, prd.t1);
+      const float dt = C.a->p.dt * ri.finestLevelCellWidth;
+      float t_i = firstSampleT(t0, dt, off);
+      float t_last = t0;
+      for (int step = 0;; t_i += dt, step++) {
+        if (step >= EXA_MAX_STEPS) { C.guardTripped = true; break; }
+        const float t_next = fminf(t_i, t1);
+        const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
+        t_last = t_next;
+        const V3 pos = ray.org + t_sample * ray.dir;
+        for (int c = 0; c < numChannels; ++c) {
+          float cellValue = 0.f;
+          V3 grad = mk(0.f, 0.f, 0.f);
+          bool doIntegrate;
+          C.count(ST_ISO_EVALS);
+          if (C.a->p.gradientShadingISO) doIntegrate = samplePoint<true, STATS>(C, cellValue, grad, ri, pos, c);
+          else                           doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
+          if (doIntegrate) {
+            isoFunc(C, last_t[c], lastCellValue[c], ray, ir, t_sample, cellValue, ri, c);
+            if (ir.pixelColor.w >= EXA_TERMINATION_THRESHOLD) break;   // leaves the channel loop only
+          }
+        }
+        if (t_next >= t1) break;
+      }
+    }
+    if (ir.t_hit >= 0.f) {
+      result.primID = EXA_PRIMID_ISOSURFACE;
+      result.t_hit = ir.t_hit / dt_scale;
+      result.Ng = normalize(ir.gradient);
+      result.ambient = 0.f;
+      result.baseColor = mk(ir.pixelColor.x, ir.pixelColor.y, ir.pixelColor.z);
+      return result;
+    }
+    alreadyIntegratedDistance = prd.t1 * (1.0000001f);
+  }
+  return result;
+}
+
+// exabrick.cu:1475-1529 traceSurfaces, implicit-iso branch
+template <bool STATS>
+__device__ __forceinline__ void traceSurfaces(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
+{
+  prd.primID = -1;
+  prd.t_hit = ray.tmax;
+  prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
+  bool activeIso = false;
+  for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
+  if (activeIso) {
+    const SurfaceHit isoPRD = traceIsoRay(C, ray, 0.f);
+    if (isoPRD.primID == EXA_PRIMID_ISOSURFACE && isoPRD.t_hit < prd.t_hit) prd = isoPRD;
+  }
+}
+
+// ------------------------------------------------------------------------
+// exabrick.cu:1576-1720 renderFrame
+// ------------------------------------------------------------------------
+template <bool GRAD, bool ISO, bool STATS>
+__global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *xfLds = reinterpret_cast<float4 *>(smem);
+  int *stackLds = reinterpret_cast<int *>(smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4));
+  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += 256) xfLds[i] = a.xf[i];
+  __syncthreads();
+
+  Ctx<STATS> C;
+  C.a = &a;
+  C.xfLds = xfLds;
+  C.stack = stackLds + threadIdx.x;
+  C.guardTripped = false;
+  if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
+
+  // tile -> pixel: wave w covers the 8x8 block (w&1, w>>1) of the 16x16 tile
+  const int tile = a.tileMap[blockIdx.x];
+  const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
+  const int px = tx * kTile + inX, py = ty * kTile + inY;
+  const bool inside = px < a.W && py < a.H;
+
+  if (inside) {
+    const ExaHipFrameState &fs = a.fs;
+    const int frameID = fs.frameID;
+    Lcg rnd;
+    rnd.init((uint32_t)(frameID * a.W * a.H) + (uint32_t)px, (uint32_t)py);      // :1591-1592
+    const float sx = float(px) + rnd.next();                                      // :1594
+    const float sy = float(py) + rnd.next();
+    Ray ray;                                                                      // Camera.h:27-44
+    ray.org = mk(fs.cam_pos);
+    ray.dir = normalize((mk(fs.cam_dir00) + sx * mk(fs.cam_dirDu)) + sy * mk(fs.cam_dirDv));
+    ray.tmin = 1e-6f; ray.tmax = 1e8f;
+
+    SurfaceHit surface;
+    surface.primID = -1; surface.t_hit = ray.tmax;
+    surface.Ng = mk(0.f, 0.f, 0.f); surface.ambient = 0.f; surface.baseColor = mk(0.f, 0.f, 0.f);
+    V3 bgColor = mk(0.f, 0.f, 0.f);
+    if (ISO) {
+      traceSurfaces(C, ray, surface);                                             // :1601
+      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE) {      // :1604-1652
+        const bool shade = surface.primID >= 0
+                        || (surface.primID == EXA_PRIMID_ISOSURFACE && a.p.gradientShadingISO);
+        if (shade && length(surface.Ng) > 0.f) {
+          const float AO_Radius = fs.ao.length;
+          const int AO_Samples = fs.ao.enabled ? 2 : 0;
+          const V3 isect_pos = ray.org + surface.t_hit * ray.dir;
+          const V3 w = surface.Ng;
+          const V3 v = fabsf(w.x) > fabsf(w.y) ? normalize(mk(-w.z, 0.f, w.x)) : normalize(mk(0.f, w.z, -w.y));
+          const V3 u = cross(v, w);
+          int hitCnt = 0;
+          for (int i = 0; i < AO_Samples; ++i) {
+            const float u1 = rnd.next(), u2 = rnd.next();
+            const float r = sqrtf(u1);
+            const float theta = 2.f * 3.14159265358979323846f * u2;
+            const V3 sp = mk(r * cosf(theta), r * sinf(theta), sqrtf(1.f - u1));
+            Ray ao_ray;
+            ao_ray.org = isect_pos;
+            ao_ray.dir = normalize((sp.x * u + sp.y * v) + sp.z * w);
+            ao_ray.tmin = 1e-4f; ao_ray.tmax = AO_Radius;
+            SurfaceHit ao;
+            traceSurfaces(C, ao_ray, ao);
+            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE) hitCnt++;
+          }
+          const float shadow = fs.ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
+          const float fd = fabsf(dot(ray.dir, surface.Ng));
+          const float ns = 1.f - shadow;
+          bgColor = mk(surface.ambient + surface.baseColor.x * fd * ns,
+                       surface.ambient + surface.baseColor.y * fd * ns,
+                       surface.ambient + surface.baseColor.z * fd * ns);
+        } else {
+          bgColor = surface.baseColor;
+        }
+      }
+    }
+
+    Color4 pixelColor; pixelColor.x = pixelColor.y = pixelColor.z = pixelColor.w = 0.f;
+    const float interleavedSamplingOffset = rnd.next();                           // :1655
+    ray.tmax = surface.t_hit;                                                     // :1657
+    if (fs.clipBox.enabled) {                                                     // clipRay :1258-1265
+      float c0, c1;
+      boxTest(ray, mk(fs.clipBox.lo), mk(fs.clipBox.hi), c0, c1);
+      ray.tmin = c0; ray.tmax = c1;
+    }
+    surface.t_hit = ray.tmax;
+
+    ray.org = xfmPoint(fs, ray.org);                                              // :1664-1668
+    ray.dir = xfmVector(fs, ray.dir);
+    const float dt_scale = length(ray.dir);
+    ray.dir = normalize(ray.dir);
+
+    float alreadyIntegratedDistance = dt_scale * ray.tmin;
+    for (int seg = 0;; seg++) {                                                   // :1675-1699
+      if (seg >= (1 << 22)) { C.guardTripped = true; break; }
+      ray.tmin = alreadyIntegratedDistance;
+      ray.tmax = surface.t_hit * dt_scale;
+      const RegionHit prd = traceRegion(C, a.volNodes, ray);
+      if (prd.leafID < 0) break;
+      C.count(ST_SEGMENTS);
+      const RegionInfo ri = a.sc.regionInfo[prd.leafID];
+      integrateBrick<GRAD, STATS>(C, pixelColor, interleavedSamplingOffset, ray, ri, prd.t0, prd.t1,
+                                  a.p.numPrimaryChannels);
+      if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) {
+        pixelColor.x = pixelColor.x * pixelColor.w;                               // :1695
+        pixelColor.y = pixelColor.y * pixelColor.w;
+        pixelColor.z = pixelColor.z * pixelColor.w;
+        pixelColor.w = 1.f;
+        break;
+      }
+      alreadyIntegratedDistance = prd.t1 * (1.0000001f);
+    }
+
+    float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;    // :1701
+    float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
+    float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
+
+    // framebuffer slot: row-major for a whole frame, tile-major inside a shard
+    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
+                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+    if (frameID > 0) {                                                            // :1709-1710
+      const float4 acc = a.accum[slot];
+      cr += acc.x; cg += acc.y; cb += acc.z;
+    }
+    a.accum[slot] = make_float4(cr, cg, cb, 1.f);                                 // :1712
+    const float div = frameID + 1.f;
+    cr = cr / div; cg = cg / div; cb = cb / div;
+    a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+  }
+
+  if (C.guardTripped) atomicExch(a.errorFlag, 1);
+  if (STATS) {
+    // wave-level reduction, one atomic per wave and counter
+    for (int i = 0; i < ST_COUNT; i++) {
+      unsigned long long v = inside ? C.st[i] : 0ull;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.stats[i], v);
+    }
+  }
+}
+
+hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s)
+{
+  if (numBlocks <= 0) return hipSuccess;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kStackDepth) * 256 * sizeof(int);
+  const dim3 grid(numBlocks), block(256);
+#define EXA_LAUNCH(G, I, S) hipLaunchKernelGGL((renderFrameKernel<G, I, S>), grid, block, lds, s, a)
+  if (stats) {
+    if (grad) { if (iso) EXA_LAUNCH(true, true, true); else EXA_LAUNCH(true, false, true); }
+    else      { if (iso) EXA_LAUNCH(false, true, true); else EXA_LAUNCH(false, false, true); }
+  } else {
+    if (grad) { if (iso) EXA_LAUNCH(true, true, false); else EXA_LAUNCH(true, false, false); }
+    else      { if (iso) EXA_LAUNCH(false, true, false); else EXA_LAUNCH(false, false, false); }
+  }
+#undef EXA_LAUNCH
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// Region activity: the OPTIX_BOUNDS_PROGRAMs (exabrick.cu:250-312, 373-402)
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void volumeActivityKernel(DeviceScene sc, ExaHipFrameState fs, ExaHipParams p,
+                                                            const float4 *xf, uint8_t *active)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *xfLds = reinterpret_cast<float4 *>(smem);
+  for (int i = threadIdx.x; i < p.numChannels * EXA_NUM_XF_VALUES; i += 256) xfLds[i] = xf[i];
+  __syncthreads();
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= sc.numRegions) return;
+  const float2 vr = sc.valueRange[r];
+  bool act = false;
+  for (int c = 0; c < p.numChannels && !act; ++c) {           // activeForVolumeSampling :250-281
+    const float dlo = fs.xfDomain[c][0], dhi = fs.xfDomain[c][1];
+    if (vr.x > dhi) continue;
+    if (vr.y < dlo) continue;
+    const float scaled_lo = (vr.x - dlo) / ((dhi - dlo) + 1e-20f);
+    const float scaled_hi = (vr.y - dlo) / ((dhi - dlo) + 1e-20f);
+    const int idx_lo = min(EXA_NUM_XF_VALUES - 1, max(0, int(scaled_lo * (EXA_NUM_XF_VALUES - 1))));
+    const int idx_hi = min(EXA_NUM_XF_VALUES - 1, max(0, int(scaled_hi * (EXA_NUM_XF_VALUES - 1)) + 1));
+    for (int i = idx_lo; i <= idx_hi; i++) {
+      float cellValue = float(i) / (EXA_NUM_XF_VALUES - 1);
+      cellValue *= dhi - dlo;
+      cellValue += dlo;
+      const Color4 rgba = lookupXF(xfLds, fs, cellValue, c);
+      if (rgba.w > 0.f) { act = true; break; }
+    }
+  }
+  active[r] = (uint8_t)(p.spaceSkippingEnabled ? (act ? 1 : 0) : 1);
+}
+
+__global__ __launch_bounds__(256) void isoActivityKernel(DeviceScene sc, ExaHipFrameState fs, uint8_t *active)
+{
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  if (r >= sc.numRegions) return;
+  const float2 vr = sc.valueRange[r];
+  bool act = false;
+  for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++)
+    if (fs.iso[i].enabled && fs.iso[i].value >= vr.x && fs.iso[i].value <= vr.y) act = true;
+  active[r] = act ? 1 : 0;
+}
+
+hipError_t launchVolumeActivity(const DeviceScene &sc, const ExaHipFrameState &fs, const ExaHipParams &p,
+                                const float4 *xf, uint8_t *active, hipStream_t s)
+{
+  if (sc.numRegions == 0) return hipSuccess;
+  const size_t lds = size_t(p.numChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
+  hipLaunchKernelGGL(volumeActivityKernel, dim3((sc.numRegions + 255) / 256), dim3(256), lds, s, sc, fs, p, xf, active);
+  return hipGetLastError();
+}
+hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, uint8_t *active, hipStream_t s)
+{
+  if (sc.numRegions == 0) return hipSuccess;
+  hipLaunchKernelGGL(isoActivityKernel, dim3((sc.numRegions + 255) / 256), dim3(256), 0, s, sc, fs, active);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// LBVH refit: one launch per height class, children before parents.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ void childBox(const BvhNode *nodes, int child, const float *domain, const uint8_t *active,
+                                         float lo[3], float hi[3])
+{
+  lo[0] = lo[1] = lo[2] = FLT_MAX;
+  hi[0] = hi[1] = hi[2] = -FLT_MAX;
+  if (child == INT32_MIN) return;                    // padding child of a one-region scene
+  if (child < 0) {
+    const int r = ~child;
+    if (!active[r]) return;
+    for (int k = 0; k < 3; k++) { lo[k] = domain[6 * size_t(r) + k]; hi[k] = domain[6 * size_t(r) + 3 + k]; }
+    return;
+  }
+  const BvhNode &n = nodes[child];
+  const float l0[3] = { n.q0.x, n.q0.y, n.q0.z }, h0[3] = { n.q0.w, n.q1.x, n.q1.y };
+  const float l1[3] = { n.q1.z, n.q1.w, n.q2.x }, h1[3] = { n.q2.y, n.q2.z, n.q2.w };
+  const bool e0 = l0[0] > h0[0], e1 = l1[0] > h1[0];
+  for (int k = 0; k < 3; k++) {
+    if (!e0) { lo[k] = fminf(lo[k], l0[k]); hi[k] = fmaxf(hi[k], h0[k]); }
+    if (!e1) { lo[k] = fminf(lo[k], l1[k]); hi[k] = fmaxf(hi[k], h1[k]); }
+  }
+}
+
+__global__ __launch_bounds__(256) void refitKernel(BvhNode *nodes, const int32_t *nodeIds, int count,
+                                                   const float *domain, const uint8_t *active)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int id = nodeIds[i];
+  BvhNode n = nodes[id];
+  float l0[3], h0[3], l1[3], h1[3];
+  childBox(nodes, n.child0, domain, active, l0, h0);
+  childBox(nodes, n.child1, domain, active, l1, h1);
+  n.q0 = make_float4(l0[0], l0[1], l0[2], h0[0]);
+  n.q1 = make_float4(h0[1], h0[2], l1[0], l1[1]);
+  n.q2 = make_float4(l1[2], h1[0], h1[1], h1[2]);
+  nodes[id] = n;
+}
+
+hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
+                       const uint8_t *active, hipStream_t s)
+{
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(refitKernel, dim3((count + 255) / 256), dim3(256), 0, s, nodes, nodeIds, count, domain, active);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// root side of the multi-GPU gather: tile-major shards -> row-major image
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void untileKernel(const uint32_t *gathered, unsigned long long shardStride,
+                                                    int world, int W, int H, int tilesX, uint32_t *out)
+{
+  const int tile = blockIdx.x;
+  const int tx = tile % tilesX, ty = tile / tilesX;
+  const int inX = threadIdx.x & 15, inY = threadIdx.x >> 4;
+  const int px = tx * kTile + inX, py = ty * kTile + inY;
+  if (px >= W || py >= H) return;
+  const int rank = tile % world;
+  // the render kernel's in-tile order: wave (w&1,w>>1) 8x8 blocks, lane = x + 8*y
+  out[size_t(px) + size_t(W) * py]
+      = gathered[size_t(rank) * shardStride + size_t(tile / world) * kTilePixels + (inY * kTile + inX)];
+}
+
+hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,
+                        int W, int H, uint32_t *out, hipStream_t s)
+{
+  const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile;
+  hipLaunchKernelGGL(untileKernel, dim3(tilesX * tilesY), dim3(256), 0, s, gathered, shardStride, world, W, H, tilesX, out);
+  return hipGetLastError();
+}
+
+} // namespace exa

@@ -1,0 +1,580 @@
+// exa_module.cpp — the exa_hip_* C ABI: scene upload, LBVH topology build,
+// dirty-flag activity/refit, frame launch.  Host side of what
+// exa/OptixRenderer.cpp does through OWL/OptiX; see include/exa_hip.h for the
+// per-entry citations.
+#include "exa_device.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace exa;
+
+namespace {
+
+thread_local std::string g_createError;
+
+#define HIP_TRY(h, call)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (h)->fail(std::string(#call) + ": " + hipGetErrorString(e_));                        \
+      return 1;                                                                            \
+    }                                                                                      \
+  } while (0)
+
+// ---- LBVH topology: Morton-sorted regions, split at the highest differing bit;
+// the depth is capped at kStackDepth so the per-lane LDS stack cannot overflow
+// (median splits once the remaining depth budget is tight). ----
+struct LbvhTopology {
+  std::vector<int32_t> child0, child1;
+  std::vector<int32_t> height;          // per internal node
+  std::vector<uint64_t> codes;
+  std::vector<uint32_t> order;
+
+  static uint64_t spread21(uint64_t v)
+  {
+    v &= 0x1fffffull;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+  }
+  static int ceilLog2(uint64_t n) { int l = 0; while ((1ull << l) < n) l++; return l; }
+
+  int32_t buildRange(size_t lo, size_t hi, int depth, int32_t &outHeight)
+  {
+    if (hi - lo == 1) { outHeight = 0; return ~int32_t(order[lo]); }
+    const int32_t me = (int32_t)child0.size();
+    child0.push_back(0); child1.push_back(0); height.push_back(0);
+    const size_t n = hi - lo;
+    size_t split = lo + (n + 1) / 2;                           // median fallback
+    const uint64_t first = codes[lo], last = codes[hi - 1];
+    if (first != last) {
+      const int prefix = __builtin_clzll(first ^ last);
+      // Karras-style search: last index whose code shares more than `prefix` leading
+      // bits with `first`; the right child starts right after it
+      size_t at = lo, step = hi - 1 - lo;
+      do {
+        step = (step + 1) >> 1;
+        const size_t cand = at + step;
+        if (cand < hi - 1) {
+          const uint64_t x = first ^ codes[cand];
+          const int pfx = x ? __builtin_clzll(x) : 64;
+          if (pfx > prefix) at = cand;
+        }
+      } while (step > 1);
+      const size_t s = at + 1;
+      const size_t big = std::max(s - lo, hi - s);
+      if (ceilLog2(big) <= kStackDepth - 1 - depth) split = s;  // keep internal depth <= kStackDepth-1
+    }
+    int32_t h0, h1;
+    const int32_t c0 = buildRange(lo, split, depth + 1, h0);
+    const int32_t c1 = buildRange(split, hi, depth + 1, h1);
+    child0[me] = c0; child1[me] = c1;
+    height[me] = 1 + std::max(h0, h1);
+    outHeight = height[me];
+    return me;
+  }
+
+  void build(const ExaBrickRegion *regions, size_t n)
+  {
+    float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::fmin(lo[k], regions[i].domain_lo[k]);
+        hi[k] = std::fmax(hi[k], regions[i].domain_hi[k]);
+      }
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
+    for (size_t i = 0; i < n; i++) {
+      uint64_t code = 0;
+      for (int k = 0; k < 3; k++) {
+        const double c = 0.5 * (double(regions[i].domain_lo[k]) + double(regions[i].domain_hi[k]));
+        const double ext = double(hi[k]) - double(lo[k]);
+        double u = ext > 0 ? (c - lo[k]) / ext : 0.0;
+        u = std::min(std::max(u, 0.0), 1.0);
+        const uint64_t q = std::min<uint64_t>(uint64_t(u * 2097152.0), 2097151ull);
+        code |= spread21(q) << k;
+      }
+      keyed[i] = { code, uint32_t(i) };
+    }
+    std::sort(keyed.begin(), keyed.end());
+    codes.resize(n); order.resize(n);
+    for (size_t i = 0; i < n; i++) { codes[i] = keyed[i].first; order[i] = keyed[i].second; }
+    child0.clear(); child1.clear(); height.clear();
+    if (n == 0) return;
+    if (n == 1) {                      // one region: a root with one real and one padding child
+      child0.push_back(~int32_t(0)); child1.push_back(INT32_MIN); height.push_back(1);
+      return;
+    }
+    child0.reserve(n); child1.reserve(n); height.reserve(n);
+    int32_t h;
+    buildRange(0, n, 0, h);
+  }
+};
+
+template <typename T>
+struct DevBuf {
+  T *p = nullptr;
+  size_t n = 0;
+  hipError_t alloc(size_t count)
+  {
+    release();
+    n = count;
+    if (count == 0) return hipSuccess;
+    return hipMalloc((void **)&p, count * sizeof(T));
+  }
+  hipError_t upload(const T *src, size_t count)
+  {
+    hipError_t e = alloc(count);
+    if (e != hipSuccess || count == 0) return e;
+    return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  ~DevBuf() { release(); }
+};
+
+} // namespace
+
+struct ExaHipRenderer {
+  int device = 0;
+  std::string err;
+  void fail(const std::string &m) { err = m; }
+
+  // scene
+  DevBuf<int4> bricks;
+  DevBuf<int32_t> leafList;
+  DevBuf<float> scalars;
+  DevBuf<RegionInfo> regionInfo;
+  DevBuf<float2> valueRange;
+  DevBuf<float> domain;
+  DeviceScene sc{};
+  int numFields = 0;
+
+  // LBVH
+  DevBuf<BvhNode> volNodes, isoNodes;
+  DevBuf<int32_t> levelIds;
+  std::vector<int> levelBegin;      // per height class, offsets into levelIds
+  std::vector<BvhNode> topoTemplate; // children filled, boxes empty (for the lazily created iso LBVH)
+  DevBuf<uint8_t> volActive, isoActive;
+  bool volDirty = true, isoDirty = true;
+
+  // state
+  DevBuf<float4> xf;
+  float xfHost[EXA_MAX_CHANNELS][EXA_NUM_XF_VALUES][4];
+  bool xfDirty = true;
+  ExaHipFrameState fs{};
+  ExaHipParams p{};
+  bool haveFs = false, haveParams = false;
+
+  // framebuffer / shard
+  int W = 0, H = 0, tilesX = 0, tilesY = 0;
+  int rank = 0, world = 1;
+  int tileOrder = 0;
+  DevBuf<float4> accum;
+  DevBuf<uint32_t> color;
+  DevBuf<int32_t> tileMap;
+  int numBlocks = 0;
+  bool layoutDirty = true;
+
+  DevBuf<unsigned long long> statsBuf;
+  DevBuf<int32_t> errorFlag;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
+  ExaHipStats last{};
+
+  bool isoEnabled() const
+  {
+    for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) if (fs.iso[i].enabled) return true;
+    return false;
+  }
+  uint64_t outputPixels() const { return uint64_t(numBlocksFor()) * kTilePixels; }
+  int numBlocksFor() const
+  {
+    const int tiles = tilesX * tilesY;
+    if (world <= 1) return tiles;
+    return tiles > rank ? (tiles - rank + world - 1) / world : 0;
+  }
+
+  int rebuildLayout()
+  {
+    tilesX = (W + kTile - 1) / kTile;
+    tilesY = (H + kTile - 1) / kTile;
+    numBlocks = numBlocksFor();
+    const size_t px = world <= 1 ? size_t(W) * H : size_t(numBlocks) * kTilePixels;
+    HIP_TRY(this, accum.alloc(px));
+    if (px) HIP_TRY(this, hipMemset(accum.p, 0, px * sizeof(float4)));
+    HIP_TRY(this, color.alloc(px));
+    std::vector<int32_t> map;
+    map.reserve(numBlocks);
+    for (int t = rank; t < tilesX * tilesY; t += world) map.push_back(t);
+    if (tileOrder == 1 && world == 1 && tilesX % 8 == 0 && tilesY % 8 == 0 && ((tilesX / 8) * (tilesY / 8)) % 8 == 0) {
+      // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs, so block b
+      // lands on XCD b%8.  Give each XCD whole 8x8-tile supertiles (128x128 px) so the
+      // rays sharing bricks also share one L2.
+      const int stx = tilesX / 8;
+      for (int b = 0; b < numBlocks; b++) {
+        const int xcd = b % 8, j = b / 8;
+        const int super = (j / 64) * 8 + xcd, in = j % 64;
+        const int sx = super % stx, sy = super / stx;
+        map[b] = (sy * 8 + in / 8) * tilesX + sx * 8 + in % 8;
+      }
+    }
+    HIP_TRY(this, tileMap.upload(map.data(), map.size()));
+    layoutDirty = false;
+    return 0;
+  }
+
+  int refit(DevBuf<BvhNode> &nodes, const uint8_t *active, hipStream_t s)
+  {
+    for (size_t h = 0; h + 1 < levelBegin.size(); h++) {
+      const int cnt = levelBegin[h + 1] - levelBegin[h];
+      HIP_TRY(this, launchRefit(nodes.p, levelIds.p + levelBegin[h], cnt, domain.p, active, s));
+    }
+    return 0;
+  }
+
+  int prepareFrame(hipStream_t s)
+  {
+    if (!haveFs || !haveParams) { fail("exa_hip_render: frame state / params not set"); return 1; }
+    if (W <= 0 || H <= 0) { fail("exa_hip_render: framebuffer not sized"); return 1; }
+    if (p.numPrimaryChannels < 1 || p.numPrimaryChannels > numFields || p.numChannels > numFields
+        || p.colormapChannel < 0 || p.colormapChannel >= numFields) {
+      fail("exa_hip_render: channel counts exceed the scene's scalar fields"); return 1;
+    }
+    if (layoutDirty && rebuildLayout()) return 1;
+    if (xfDirty) {
+      HIP_TRY(this, hipMemcpyAsync(xf.p, xfHost, sizeof(xfHost), hipMemcpyHostToDevice, s));
+      xfDirty = false;
+    }
+    const bool needIso = isoEnabled();
+    if (volDirty || (needIso && isoDirty)) {
+      HIP_TRY(this, hipEventRecord(ev2, s));
+      if (volDirty) {                       // needVolumeBVHRebuild (OptixRenderer.cpp:533-537)
+        HIP_TRY(this, launchVolumeActivity(sc, fs, p, xf.p, volActive.p, s));
+        if (refit(volNodes, volActive.p, s)) return 1;
+        volDirty = false;
+      }
+      if (needIso && isoDirty) {            // needIsoBVHRebuild (OptixRenderer.cpp:539-543)
+        if (!isoNodes.p && !topoTemplate.empty())
+          HIP_TRY(this, isoNodes.upload(topoTemplate.data(), topoTemplate.size()));
+        HIP_TRY(this, launchIsoActivity(sc, fs, isoActive.p, s));
+        if (refit(isoNodes, isoActive.p, s)) return 1;
+        isoDirty = false;
+      }
+      HIP_TRY(this, hipEventRecord(ev1, s));
+      HIP_TRY(this, hipEventSynchronize(ev1));
+      HIP_TRY(this, hipEventElapsedTime(&last.rebuild_ms, ev2, ev1));
+    }
+    return 0;
+  }
+
+  int launch(uint32_t *dstDevice, bool stats, hipStream_t s)
+  {
+    RenderArgs a{};
+    a.sc = sc;
+    a.volNodes = volNodes.p;
+    a.isoNodes = isoNodes.p;
+    a.fs = fs;
+    a.p = p;
+    a.xf = xf.p;
+    a.numXfChannels = numFields;
+    a.W = W; a.H = H; a.tilesX = tilesX; a.tilesY = tilesY;
+    a.rank = rank; a.world = world;
+    a.tileMap = tileMap.p;
+    a.color = dstDevice;
+    a.accum = accum.p;
+    a.stats = statsBuf.p;
+    a.errorFlag = errorFlag.p;
+    HIP_TRY(this, hipEventRecord(ev0, s));
+    HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, isoEnabled(), stats, s));
+    HIP_TRY(this, hipEventRecord(ev1, s));
+    return 0;
+  }
+};
+
+extern "C" {
+
+const char *exa_hip_last_error(const ExaHipRenderer *h) { return h ? h->err.c_str() : g_createError.c_str(); }
+
+int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **out)
+{
+  if (!out || !scene) { g_createError = "exa_hip_create: null argument"; return 1; }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_createError = std::string("exa_hip_create: no HIP device available (") + hipGetErrorString(e)
+                  + "); this module has no CPU fallback";
+    return 2;
+  }
+  if (device < 0 || device >= ndev) { g_createError = "exa_hip_create: bad device index"; return 1; }
+  if (scene->numFields < 1 || scene->numFields > EXA_MAX_CHANNELS) { g_createError = "exa_hip_create: 1..10 scalar fields required"; return 1; }
+  if (scene->numRegions == 0 || scene->numBricks == 0) { g_createError = "exa_hip_create: empty scene"; return 1; }
+  if (scene->numRegions > 0x7fffffffull) { g_createError = "exa_hip_create: too many regions"; return 1; }
+  ExaHipRenderer *h = new ExaHipRenderer;
+  h->device = device;
+  auto bail = [&]() { g_createError = h->err; delete h; return 1; };
+#define CREATE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return bail(); } } while (0)
+  CREATE_TRY(hipSetDevice(device));
+
+  // validate indices on the host before anything can fault on the device
+  for (uint64_t i = 0; i < scene->leafListSize; i++)
+    if (scene->leafList[i] < 0 || uint64_t(scene->leafList[i]) >= scene->numBricks) { h->fail("exa_hip_create: leaf list entry out of range"); return bail(); }
+  for (uint64_t b = 0; b < scene->numBricks; b++) {
+    const ExaBrick &B = scene->bricks[b];
+    const uint64_t vol = uint64_t(B.size[0]) * uint64_t(B.size[1]) * uint64_t(B.size[2]);
+    if (B.size[0] <= 0 || B.size[1] <= 0 || B.size[2] <= 0 || B.level < 0 || B.level > 30
+        || uint64_t(B.begin) + vol > scene->totalCells) { h->fail("exa_hip_create: brick record out of range"); return bail(); }
+  }
+  for (int f = 0; f < scene->numFields; f++)
+    if (scene->channelOffset[f] + scene->totalCells > uint64_t(scene->numFields) * scene->totalCells) { h->fail("exa_hip_create: channel offset out of range"); return bail(); }
+
+  h->numFields = scene->numFields;
+  static_assert(sizeof(ExaBrick) == 2 * sizeof(int4), "brick = two int4");
+  CREATE_TRY(h->bricks.upload(reinterpret_cast<const int4 *>(scene->bricks), scene->numBricks * 2));
+  CREATE_TRY(h->leafList.upload(scene->leafList, scene->leafListSize));
+  CREATE_TRY(h->scalars.upload(scene->scalars, size_t(scene->numFields) * scene->totalCells));
+  std::vector<RegionInfo> ri(scene->numRegions);
+  std::vector<float2> vr(scene->numRegions);
+  std::vector<float> dom(scene->numRegions * 6);
+  for (uint64_t r = 0; r < scene->numRegions; r++) {
+    const ExaBrickRegion &R = scene->regions[r];
+    if (R.leafListSize < 1 || R.leafListBegin < 0 || uint64_t(R.leafListBegin) + uint64_t(R.leafListSize) > scene->leafListSize) {
+      h->fail("exa_hip_create: region leaf list out of range"); return bail();
+    }
+    ri[r].listBegin = R.leafListBegin;
+    ri[r].listSize = R.leafListSize;
+    ri[r].finestLevelCellWidth = R.finestLevelCellWidth;
+    ri[r].firstBrick = scene->leafList[R.leafListBegin];
+    vr[r] = make_float2(R.valueRange_lo, R.valueRange_hi);
+    for (int k = 0; k < 3; k++) { dom[6 * r + k] = R.domain_lo[k]; dom[6 * r + 3 + k] = R.domain_hi[k]; }
+  }
+  CREATE_TRY(h->regionInfo.upload(ri.data(), ri.size()));
+  CREATE_TRY(h->valueRange.upload(vr.data(), vr.size()));
+  CREATE_TRY(h->domain.upload(dom.data(), dom.size()));
+
+  // LBVH topology (host), boxes are filled by the first refit
+  LbvhTopology topo;
+  topo.build(scene->regions, scene->numRegions);
+  const size_t ni = topo.child0.size();
+  h->topoTemplate.resize(ni);
+  for (size_t i = 0; i < ni; i++) {
+    BvhNode &n = h->topoTemplate[i];
+    n.q0 = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX);
+    n.q1 = make_float4(-FLT_MAX, -FLT_MAX, FLT_MAX, FLT_MAX);
+    n.q2 = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+    n.child0 = topo.child0[i]; n.child1 = topo.child1[i]; n.pad0 = n.pad1 = 0;
+  }
+  CREATE_TRY(h->volNodes.upload(h->topoTemplate.data(), ni));
+  int maxH = 0;
+  for (size_t i = 0; i < ni; i++) maxH = std::max(maxH, topo.height[i]);
+  std::vector<int> count(maxH + 2, 0);
+  for (size_t i = 0; i < ni; i++) count[topo.height[i]]++;
+  h->levelBegin.assign(1, 0);
+  for (int hh = 1; hh <= maxH; hh++) h->levelBegin.push_back(h->levelBegin.back() + count[hh]);
+  std::vector<int32_t> ids(ni);
+  {
+    std::vector<int> cursor(h->levelBegin.begin(), h->levelBegin.end());
+    for (size_t i = 0; i < ni; i++) ids[cursor[topo.height[i] - 1]++] = (int32_t)i;
+  }
+  CREATE_TRY(h->levelIds.upload(ids.data(), ids.size()));
+  CREATE_TRY(h->volActive.alloc(scene->numRegions));
+  CREATE_TRY(h->isoActive.alloc(scene->numRegions));
+  CREATE_TRY(h->xf.alloc(size_t(EXA_MAX_CHANNELS) * EXA_NUM_XF_VALUES));
+  std::memset(h->xfHost, 0, sizeof(h->xfHost));
+  CREATE_TRY(h->statsBuf.alloc(ST_COUNT));
+  CREATE_TRY(h->errorFlag.alloc(1));
+  CREATE_TRY(hipMemset(h->errorFlag.p, 0, sizeof(int32_t)));
+  CREATE_TRY(hipEventCreate(&h->ev0));
+  CREATE_TRY(hipEventCreate(&h->ev1));
+  CREATE_TRY(hipEventCreate(&h->ev2));
+
+  h->sc.bricks = h->bricks.p;
+  h->sc.leafList = h->leafList.p;
+  h->sc.scalars = h->scalars.p;
+  h->sc.regionInfo = h->regionInfo.p;
+  h->sc.valueRange = h->valueRange.p;
+  h->sc.domain = h->domain.p;
+  for (int f = 0; f < EXA_MAX_CHANNELS; f++) h->sc.channelOffset[f] = f < scene->numFields ? scene->channelOffset[f] : 0;
+  h->sc.numRegions = (uint32_t)scene->numRegions;
+  h->sc.numInternal = (uint32_t)ni;
+#undef CREATE_TRY
+  *out = h;
+  return 0;
+}
+
+int exa_hip_destroy(ExaHipRenderer *h)
+{
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  if (h->ev2) (void)hipEventDestroy(h->ev2);
+  delete h;
+  return 0;
+}
+
+int exa_hip_resize(ExaHipRenderer *h, int32_t width, int32_t height)
+{
+  if (!h) return 1;
+  if (width <= 0 || height <= 0 || int64_t(width) * height > (int64_t(1) << 30)) { h->fail("exa_hip_resize: bad size"); return 1; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  h->W = width; h->H = height;
+  h->layoutDirty = true;
+  return h->rebuildLayout();
+}
+
+int exa_hip_set_frame_state(ExaHipRenderer *h, const ExaHipFrameState *fs)
+{
+  if (!h || !fs) return 1;
+  if (!h->haveFs || std::memcmp(h->fs.xfDomain, fs->xfDomain, sizeof(fs->xfDomain)) != 0
+      || h->fs.xfOpacityScale != fs->xfOpacityScale) h->volDirty = true;
+  if (!h->haveFs || std::memcmp(h->fs.iso, fs->iso, sizeof(fs->iso)) != 0) h->isoDirty = true;
+  h->fs = *fs;
+  h->haveFs = true;
+  return 0;
+}
+
+int exa_hip_set_xf(ExaHipRenderer *h, int32_t chan, const float *rgba128)
+{
+  if (!h || !rgba128) return 1;
+  if (chan < 0 || chan >= EXA_MAX_CHANNELS) { h->fail("exa_hip_set_xf: bad channel"); return 1; }
+  std::memcpy(h->xfHost[chan], rgba128, sizeof(h->xfHost[chan]));
+  h->xfDirty = true;
+  h->volDirty = true;                      // needVolumeBVHRebuild = true (OptixRenderer.cpp:403)
+  return 0;
+}
+
+int exa_hip_set_params(ExaHipRenderer *h, const ExaHipParams *p)
+{
+  if (!h || !p) return 1;
+  if (!(p->dt > 0.f)) { h->fail("exa_hip_set_params: dt must be > 0"); return 1; }
+  if (!h->haveParams || h->p.numChannels != p->numChannels || h->p.spaceSkippingEnabled != p->spaceSkippingEnabled)
+    h->volDirty = true;
+  h->p = *p;
+  h->haveParams = true;
+  return 0;
+}
+
+int exa_hip_set_shard(ExaHipRenderer *h, int32_t rank, int32_t worldSize)
+{
+  if (!h) return 1;
+  if (worldSize < 1 || rank < 0 || rank >= worldSize) { h->fail("exa_hip_set_shard: bad rank/world"); return 1; }
+  h->rank = rank; h->world = worldSize;
+  h->layoutDirty = true;
+  if (h->W > 0) { HIP_TRY(h, hipSetDevice(h->device)); return h->rebuildLayout(); }
+  return 0;
+}
+
+int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
+{
+  if (!h || !key) return 1;
+  if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
+  h->fail(std::string("exa_hip_set_option: unknown key ") + key);
+  return 1;
+}
+
+uint64_t exa_hip_output_pixels(const ExaHipRenderer *h)
+{
+  if (!h || h->W <= 0) return 0;
+  return h->world <= 1 ? uint64_t(h->W) * h->H : h->outputPixels();
+}
+
+static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, hipStream_t s, bool async, bool stats)
+{
+  if (!h) return 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->prepareFrame(s)) return 1;
+  uint32_t *dst = dstIsDevice && rgba8 ? rgba8 : h->color.p;
+  if (stats) HIP_TRY(h, hipMemsetAsync(h->statsBuf.p, 0, ST_COUNT * sizeof(unsigned long long), s));
+  if (h->launch(dst, stats, s)) return 1;
+  if (async && dstIsDevice && !stats) return 0;
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  HIP_TRY(h, hipEventElapsedTime(&h->last.kernel_ms, h->ev0, h->ev1));
+  const size_t px = (size_t)exa_hip_output_pixels(h);
+  if (!dstIsDevice && rgba8) HIP_TRY(h, hipMemcpy(rgba8, h->color.p, px * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  int32_t flag = 0;
+  HIP_TRY(h, hipMemcpy(&flag, h->errorFlag.p, sizeof(flag), hipMemcpyDeviceToHost));
+  if (flag) {
+    (void)hipMemset(h->errorFlag.p, 0, sizeof(int32_t));
+    h->fail("exa_hip_render: a ray-march loop guard tripped (step size too small for the ray length?)");
+    return 3;
+  }
+  if (stats) {
+    unsigned long long c[ST_COUNT];
+    HIP_TRY(h, hipMemcpy(c, h->statsBuf.p, sizeof(c), hipMemcpyDeviceToHost));
+    h->last.segments = c[ST_SEGMENTS]; h->last.sample_evals = c[ST_SAMPLE_EVALS]; h->last.samples = c[ST_SAMPLES];
+    h->last.brick_visits = c[ST_BRICK_VISITS]; h->last.corner_loads = c[ST_CORNER_LOADS];
+    h->last.iso_segments = c[ST_ISO_SEGMENTS]; h->last.iso_evals = c[ST_ISO_EVALS]; h->last.nodes_visited = c[ST_NODES];
+  }
+  h->last.pixels = px;
+  return 0;
+}
+
+int exa_hip_render(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, void *hipStream, int32_t async)
+{ return renderImpl(h, rgba8, dstIsDevice, (hipStream_t)hipStream, async != 0, false); }
+
+int exa_hip_render_stats(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, ExaHipStats *out)
+{
+  const int rc = renderImpl(h, rgba8, dstIsDevice, nullptr, false, true);
+  if (rc == 0 && out) *out = h->last;
+  return rc;
+}
+
+int exa_hip_get_stats(ExaHipRenderer *h, ExaHipStats *out)
+{
+  if (!h || !out) return 1;
+  // refresh the kernel time of an async launch if it has completed
+  if (h->ev0 && hipEventQuery(h->ev1) == hipSuccess) (void)hipEventElapsedTime(&h->last.kernel_ms, h->ev0, h->ev1);
+  *out = h->last;
+  return 0;
+}
+
+int exa_hip_untile(ExaHipRenderer *h, const uint32_t *gathered, uint64_t shardStridePixels,
+                   int32_t worldSize, uint32_t *rgba8_out, void *hipStream)
+{
+  if (!h || !gathered || !rgba8_out || worldSize < 1) return 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, launchUntile(gathered, shardStridePixels, worldSize, h->W, h->H, rgba8_out, (hipStream_t)hipStream));
+  return 0;
+}
+
+int exa_hip_read_accum(ExaHipRenderer *h, float *dst4)
+{
+  if (!h || !dst4) return 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy(dst4, h->accum.p, h->accum.n * sizeof(float4), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int exa_hip_write_accum(ExaHipRenderer *h, const float *src4)
+{
+  if (!h || !src4) return 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipMemcpy(h->accum.p, src4, h->accum.n * sizeof(float4), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int exa_hip_read_activity(ExaHipRenderer *h, int32_t which, uint8_t *dst)
+{
+  if (!h || !dst) return 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  if (h->prepareFrame(nullptr)) return 1;
+  if (which == 1 && !h->isoEnabled()) {     // evaluate on demand
+    HIP_TRY(h, launchIsoActivity(h->sc, h->fs, h->isoActive.p, nullptr));
+  }
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(dst, which ? h->isoActive.p : h->volActive.p, h->sc.numRegions, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+} // extern "C"

@@ -115,3 +115,102 @@ def with_extra_field(scene, fn):
     ctr = cells[:, :3] + 0.5 * cw[:, None]
     scene.fields.append(fn(ctr).astype(np.float32))
     return scene
+
+
+# ---------------------------------------------------------------------------
+# procedural block-structured AMR scenes (seeded; stand-ins for the real data
+# sets, none of which ship with the reference)
+# ---------------------------------------------------------------------------
+def _splitmix64(x):
+    x = (x + np.uint64(0x9E3779B97F4A7C15)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = x
+    z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & np.uint64(0xFFFFFFFFFFFFFFFF)
+    return z ^ (z >> np.uint64(31))
+
+
+def _hash01(ix, iy, iz, seed):
+    with np.errstate(over="ignore"):
+        k = (ix.astype(np.uint64) * np.uint64(0x9E3779B1) ^ iy.astype(np.uint64) * np.uint64(0x85EBCA77)
+             ^ iz.astype(np.uint64) * np.uint64(0xC2B2AE3D) ^ np.uint64(seed))
+        return (_splitmix64(k) >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+
+
+def _value_noise(p, cell, seed):
+    """trilinear value noise with lattice spacing `cell`."""
+    q = p / cell
+    i = np.floor(q).astype(np.int64)
+    f = q - i
+    f = f * f * (3 - 2 * f)
+    out = 0.0
+    for dz in (0, 1):
+        for dy in (0, 1):
+            for dx in (0, 1):
+                w = (f[:, 0] if dx else 1 - f[:, 0]) * (f[:, 1] if dy else 1 - f[:, 1]) * (f[:, 2] if dz else 1 - f[:, 2])
+                out = out + w * _hash01(i[:, 0] + dx, i[:, 1] + dy, i[:, 2] + dz, seed)
+    return out
+
+
+def amr(seed=1, root=(3, 3, 2), B=4, levels=3, feature="shell", fields=1, name=None):
+    """Octree of B^3-cell blocks: root blocks at level levels-1 are refined toward a
+    feature surface down to level 0; every leaf block is one brick (dense, single
+    level, disjoint).  Voxel space = finest-level cell units."""
+    top = levels - 1
+    ext = np.array(root, dtype=np.float64) * B * (1 << top)
+    centre = ext * np.array([0.45, 0.55, 0.5])
+    radius = 0.3 * float(ext.min())
+
+    def sdf(p):
+        if feature == "shell":
+            return np.abs(np.linalg.norm(p - centre, axis=-1) - radius)
+        if feature == "plume":
+            d1 = np.abs(np.linalg.norm(p - centre, axis=-1) - radius)
+            q = p - centre
+            d2 = np.sqrt(q[..., 0] ** 2 + q[..., 2] ** 2) - 0.08 * float(ext.min())
+            return np.minimum(d1, np.abs(d2))
+        raise ValueError(feature)
+
+    bricks = []
+    stack = [(x * B << top, y * B << top, z * B << top, top)
+             for z in range(root[2]) for y in range(root[1]) for x in range(root[0])][::-1]
+    rng_seed = int(seed)
+    while stack:
+        x, y, z, l = stack.pop()
+        e = B << l
+        c = np.array([x + e / 2, y + e / 2, z + e / 2], dtype=np.float64)
+        jitter = float(_hash01(np.array([x]), np.array([y]), np.array([z + 7919 * l]), rng_seed)[0])
+        if l > 0 and sdf(c) < (0.6 + 0.5 * jitter) * e:
+            h = e // 2
+            kids = [(x + dx * h, y + dy * h, z + dz * h, l - 1) for dz in (0, 1) for dy in (0, 1) for dx in (0, 1)]
+            stack.extend(kids[::-1])
+        else:
+            bricks.append((B, B, B, x, y, z, l))
+    bricks7 = np.array(bricks, dtype=np.int32)
+    n = bricks7.shape[0]
+    # cell centres in brick order (x fastest)
+    k = np.arange(B)
+    KZ, KY, KX = np.meshgrid(k, k, k, indexing="ij")
+    off = np.stack([KX.ravel(), KY.ravel(), KZ.ravel()], axis=1).astype(np.float64)  # [B^3,3]
+    cw = (1 << bricks7[:, 6]).astype(np.float64)
+    ctr = (bricks7[:, None, 3:6].astype(np.float64) + (off[None] + 0.5) * cw[:, None, None]).reshape(-1, 3)
+    out_fields = []
+    for f in range(fields):
+        d = np.linalg.norm(ctr - centre, axis=1) / (0.5 * float(np.linalg.norm(ext)))
+        base = np.clip(1.0 - d, 0, 1) if f == 0 else 0.5 + 0.5 * np.sin(ctr[:, f % 3] * (6.0 / ext[f % 3]))
+        noise = _value_noise(ctr, 0.31 * float(ext.min()), seed + 101 * f) * 0.5 \
+            + _value_noise(ctr, 0.13 * float(ext.min()), seed + 101 * f + 17) * 0.25
+        out_fields.append((0.55 * base + 0.6 * noise).astype(np.float32))
+    # scramble cell IDs so the gather by cellID is exercised (fields are indexed by cellID)
+    total = n * B ** 3
+    perm = np.argsort(_hash01(np.arange(total), np.zeros(total, dtype=np.int64), np.zeros(total, dtype=np.int64), seed + 5))
+    cellIDs = perm.astype(np.int32)
+    fields_by_id = []
+    for fld in out_fields:
+        g = np.empty_like(fld)
+        g[cellIDs] = fld
+        fields_by_id.append(g)
+    sc = Scene(bricks7, cellIDs, fields_by_id, name=name or f"amr_{feature}_{seed}")
+    f0 = fields_by_id[0]
+    sc.value_range = (float(min(f0.min(), 0.0)), float(max(f0.max(), 0.0)))
+    sc.meta.update(dict(B=B, levels=levels, extent=ext.tolist()))
+    return sc

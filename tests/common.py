@@ -1,0 +1,145 @@
+"""Shared machinery of the parity tests: one `Case` = scene + camera + transfer
+function + settings, runnable through the CPU oracle and through the HIP module
+(via the C ABI) with identical inputs."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import pyoracle as po  # noqa: E402  (tests are allowed to use the oracle)
+from owlexabrick_amd import harness, scenes  # noqa: E402
+
+
+def ramp_xf(seed=0):
+    return harness.default_xf()
+
+
+def band_xf(lo=0.35, hi=0.65):
+    """opacity only inside a value band -> many regions inactive (space skipping)."""
+    xf = harness.default_xf()
+    t = np.arange(128) / 127.0
+    xf[:, 3] = np.where((t >= lo) & (t <= hi), 0.6, 0.0)
+    return xf
+
+
+class Case:
+    def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
+                 space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
+                 xfm=None, grad_iso=1, multi=True, xf_domains=None):
+        self.scene, self.W, self.H = scene, W, H
+        self.grad, self.iso, self.dt = grad, iso, dt
+        self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
+        self.opacity_scale, self.space_skipping = opacity_scale, space_skipping
+        self.ao, self.ao_length, self.clip, self.frameID = ao, ao_length, clip, frameID
+        self.camera, self.xfm, self.grad_iso, self.multi = camera, xfm, grad_iso, multi
+        nf = len(scene.fields)
+        self.nprim = nf if multi else 1
+        self.colormap_channel = 0 if (multi or nf < 2) else 1
+        if xf_domains is None:
+            xf_domains = []
+            for f in scene.fields:
+                xf_domains.append((float(min(f.min(), 0.0)), float(max(f.max(), 0.0))))
+        self.xf_domains = xf_domains
+
+    def cam(self, lo, hi):
+        if self.camera is not None:
+            return harness.camera(self.camera[0], self.camera[1], self.camera[2], self.camera[3], self.W, self.H)
+        if self.xfm is not None:
+            # world bounds = inverse-transformed voxel bounds; tests pass world camera explicitly instead
+            raise ValueError("xfm cases need an explicit camera")
+        return harness.default_camera(lo, hi, self.W, self.H)
+
+    # ---- oracle ----
+    def oracle_scene(self):
+        S = po.OracleScene(self.scene.bricks7, self.scene.cellIDs, self.scene.fields,
+                           num_region_fields=len(self.scene.fields) if self.multi else 1)
+        for c, xf in enumerate(self.xfs):
+            S.set_xf(c, xf)
+        return S
+
+    def oracle_state(self, S, frameID=None):
+        lo, hi = S.voxel_bounds()
+        fs = po.FrameState()
+        harness.fill_frame_state(fs, self.cam(lo, hi), self.xf_domains, xfOpacityScale=self.opacity_scale,
+                                 frameID=self.frameID if frameID is None else frameID, iso=self.iso,
+                                 clip=self.clip, ao_enabled=self.ao, ao_length=self.ao_length, xfm=self.xfm)
+        P = po.Params(self.dt, self.nprim, self.colormap_channel, self.grad, self.grad_iso, self.nprim,
+                      self.space_skipping)
+        return fs, P
+
+    def run_oracle(self, nthreads=8, frames=1, window=None):
+        S = self.oracle_scene()
+        acc, out = None, None
+        for f in range(frames):
+            fs, P = self.oracle_state(S, frameID=self.frameID + f)
+            rgba, acc, st = S.render(fs, P, self.W, self.H, window=window, accum=acc, nthreads=nthreads)
+            out = (rgba, acc, st)
+        return out
+
+    # ---- HIP module through the C ABI ----
+    def hip_renderer(self, device=0):
+        from owlexabrick_amd import binding
+        prep = binding.Prep(self.scene, num_region_fields=len(self.scene.fields) if self.multi else 1)
+        R = binding.Renderer(prep, device=device, multiFieldDvr=self.multi)
+        lo, hi = prep.voxel_bounds()
+        cam = self.cam(lo, hi)
+        if self.xfm is not None:
+            R.setVoxelSpaceTransform(self.xfm["vx"], self.xfm["vy"], self.xfm["vz"], self.xfm["p"])
+        R.resizeFrameBuffer((self.W, self.H))
+        R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
+        for c, xf in enumerate(self.xfs):
+            R.updateXF(c, xf[:, 3], xf[:, :3], self.xf_domains[c], self.opacity_scale)
+        iso_v, iso_c, iso_e = [0.0, 0.0], [0, 0], [0, 0]
+        for i, spec in enumerate(self.iso or []):
+            iso_v[i], iso_c[i], iso_e[i] = spec[0], spec[1], 1
+        R.updateIsoValues(iso_v, iso_c, iso_e)
+        R.setSpaceSkipping(bool(self.space_skipping))
+        R.setGradientShadingDVR(bool(self.grad))
+        R.setGradientShadingISO(bool(self.grad_iso))
+        R.updateDt(self.dt)
+        R.frameState.ao.enabled, R.frameState.ao.length = int(self.ao), float(self.ao_length)   # viewer.cpp:946-956
+        R.frameState.clipBox.enabled = 0
+        if self.clip is not None:
+            R.frameState.clipBox.enabled = 1
+            for i in range(3):
+                R.frameState.clipBox.lo[i], R.frameState.clipBox.hi[i] = float(self.clip[0][i]), float(self.clip[1][i])
+        return R
+
+    def run_hip(self, frames=1, stats=False):
+        R = self.hip_renderer()
+        out = None
+        for f in range(frames):
+            R.updateFrameID(self.frameID + f)       # viewer.cpp:281-288
+            if stats and f == frames - 1:
+                rgba, st = R.renderStats()
+            else:
+                rgba, st = R.render(), None
+            out = (rgba, R.readAccum(), st)
+        R.close()
+        return out
+
+
+# Float tolerance of CPU-vs-GPU parity (stated in DESIGN.md): the two sides differ
+# only in libm vs OCML powf/cosf/sinf (<= 2 ulp); everything else is the same
+# IEEE operation sequence.
+ACCUM_ATOL = 2e-5
+ACCUM_RTOL = 1e-4
+RGBA_MAX_LSB = 1
+
+
+def compare(oracle_out, hip_out, what=""):
+    o_rgba, o_acc, _ = oracle_out
+    h_rgba, h_acc, _ = hip_out
+    da = np.abs(o_acc.astype(np.float64) - h_acc.astype(np.float64))
+    tol = ACCUM_ATOL + ACCUM_RTOL * np.abs(o_acc)
+    o8 = harness.unpack_rgba8(o_rgba).astype(np.int32)
+    h8 = harness.unpack_rgba8(h_rgba).astype(np.int32)
+    d8 = np.abs(o8 - h8)
+    return dict(what=what, accum_max=float(da.max()), accum_bad=int((da > tol).sum()),
+                rgba_max=int(d8.max()), rgba_bad=int((d8 > RGBA_MAX_LSB).sum()),
+                rgba_diff_px=int((d8.max(axis=-1) > 0).sum()), exact=bool(np.array_equal(o_acc, h_acc)))
