@@ -11,10 +11,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -167,7 +170,7 @@ struct ExaPrep {
   std::vector<ExaBrick>       bricks;
   std::vector<ExaBrickRegion> regions;
   std::vector<int32_t>        leafList;
-  std::vector<float>          scalars;
+  std::unique_ptr<float[]>    scalars;        // numFields * totalCells, first touched in parallel
   std::vector<uint64_t>       channelOffset;
   uint64_t totalCells = 0;
   int32_t  numFields = 0;
@@ -183,7 +186,7 @@ void valueRangeOf(const ExaPrep &P, ExaBrickRegion &R, int numRegionFields)
 {
   float lo = std::numeric_limits<float>::infinity(), hi = -lo;
   for (int f = 0; f < numRegionFields; f++) {
-    const float *field = P.scalars.data() + P.channelOffset[f];
+    const float *field = P.scalars.get() + P.channelOffset[f];
     for (int i = 0; i < R.leafListSize; i++) {
       const ExaBrick &b = P.bricks[P.leafList[R.leafListBegin + i]];
       const float cw = float(1 << b.level);
@@ -232,6 +235,10 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
   if (numThreads <= 0) numThreads = (int)std::max(1u, std::thread::hardware_concurrency());
   if (numRegionFields < 0 || numRegionFields > numFields) numRegionFields = numFields;
   ExaPrep *P = new ExaPrep;
+  const bool verbose = std::getenv("EXA_PREP_VERBOSE") != nullptr;
+  auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  double tPhase = now();
+  auto lap = [&](const char *what) { if (verbose) { const double t = now(); std::fprintf(stderr, "[exa_prep] %-10s %.3f s\n", what, t - tPhase); tPhase = t; } };
   auto fail = [&](const char *msg) { g_prepError = msg; delete P; return 1; };
 
   // ---- flatten (exa/OptixRenderer.cpp:71-93) ----
@@ -257,13 +264,14 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
   if (running != numCellIDs) return fail("failed sanity-check in brick size");
   P->totalCells = running;
 
+  lap("flatten");
   // ---- gather scalars into brick order (exa/OptixRenderer.cpp:103-132) ----
-  P->scalars.resize(size_t(numFields) * P->totalCells);
+  P->scalars.reset(new float[size_t(numFields) * P->totalCells]);
   P->channelOffset.resize(numFields);
   std::atomic<int> bad{0};
   for (int f = 0; f < numFields; f++) {
     P->channelOffset[f] = uint64_t(f) * P->totalCells;
-    float *dst = P->scalars.data() + P->channelOffset[f];
+    float *dst = P->scalars.get() + P->channelOffset[f];
     const float *src = fields[f];
     const uint64_t len = fieldLen[f];
     parallelChunks(P->totalCells, numThreads, [&](size_t b, size_t e) {
@@ -278,6 +286,7 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
   if (bad == 1) return fail("overflow in index vector...");
   if (bad == 2) return fail("invalid cell ID");
 
+  lap("gather");
   // ---- same-bricks regions (exa/Regions.cpp:242-320) ----
   std::vector<BuildPrim> prims(numBricks);
   float blo[3] = { INFINITY, INFINITY, INFINITY }, bhi[3] = { -INFINITY, -INFINITY, -INFINITY };
@@ -299,6 +308,7 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
   P->regions = std::move(all.regions);
   P->leafList = std::move(all.leafList);
 
+  lap("partition");
   // finest level + value range per region (exa/Regions.cpp:290-306)
   parallelChunks(P->regions.size(), numThreads, [&](size_t b, size_t e) {
     for (size_t r = b; r < e; r++) {
@@ -310,6 +320,7 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
       valueRangeOf(*P, R, numRegionFields);
     }
   });
+  lap("ranges");
   *out = P;
   return 0;
 }
@@ -322,7 +333,7 @@ int exa_prep_scene(const ExaPrep *P, ExaHipScene *out)
   out->bricks = P->bricks.data();               out->numBricks = P->bricks.size();
   out->regions = P->regions.data();             out->numRegions = P->regions.size();
   out->leafList = P->leafList.data();           out->leafListSize = P->leafList.size();
-  out->scalars = P->scalars.data();
+  out->scalars = P->scalars.get();
   out->channelOffset = P->channelOffset.data();
   out->totalCells = P->totalCells;
   out->numFields = P->numFields;

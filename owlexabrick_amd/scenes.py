@@ -214,3 +214,91 @@ def amr(seed=1, root=(3, 3, 2), B=4, levels=3, feature="shell", fields=1, name=N
     sc.value_range = (float(min(f0.min(), 0.0)), float(max(f0.max(), 0.0)))
     sc.meta.update(dict(B=B, levels=levels, extent=ext.tolist()))
     return sc
+
+
+# ---------------------------------------------------------------------------
+# large seeded scenes from tools/libexa_scenegen.so (C++, multi-threaded)
+# ---------------------------------------------------------------------------
+KINDS = {"lanl": 0, "gear": 1, "exajet": 2}
+
+# BASELINE.json configs 2..4 as procedural stand-ins; `band` tunes the
+# refinement band so that the cell counts land near the targets
+CONFIGS = {
+    "c2_lanl":   dict(kind="lanl",   seed=0xE7A0001, root=(18, 18, 9), B=8, levels=4, band=1.0, fields=1),
+    "c3_gear":   dict(kind="gear",   seed=0xE7A0002, root=(32, 48, 32), B=8, levels=4, band=1.0, fields=2),
+    "c4_exajet": dict(kind="exajet", seed=0xE7A0003, root=(64, 32, 32), B=8, levels=4, band=2.5, fields=1),
+}
+
+
+def _scenegen_lib():
+    import ctypes as C
+    import os
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    path = os.path.join(here, "libexa_scenegen.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", here, "-s"])
+    L = C.CDLL(path)
+    L.exa_scenegen_create.argtypes = [C.c_uint64, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                      C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.exa_scenegen_destroy.argtypes = [C.c_void_p]
+    for n in ("exa_scenegen_num_bricks", "exa_scenegen_num_cells"):
+        getattr(L, n).restype = C.c_uint64
+        getattr(L, n).argtypes = [C.c_void_p]
+    for n in ("exa_scenegen_bricks7", "exa_scenegen_cell_ids"):
+        getattr(L, n).restype = C.c_void_p
+        getattr(L, n).argtypes = [C.c_void_p]
+    L.exa_scenegen_field.restype = C.c_void_p
+    L.exa_scenegen_field.argtypes = [C.c_void_p, C.c_int32]
+    L.exa_scenegen_level_histogram.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    return L
+
+
+class _GenHandle:
+    def __init__(self, L, h):
+        self.L, self.h = L, h
+
+    def __del__(self):
+        if self.h:
+            self.L.exa_scenegen_destroy(self.h)
+            self.h = None
+
+
+def generated(kind="exajet", seed=1, root=(8, 4, 4), B=8, levels=4, band=1.0, fields=1, threads=0,
+              fill=True, name=None):
+    """seeded AMR scene from the C++ generator; arrays are views on the generator's memory."""
+    import ctypes as C
+    L = _scenegen_lib()
+    h = C.c_void_p()
+    rootN = (C.c_int32 * 3)(*root)
+    rc = L.exa_scenegen_create(seed, rootN, B, levels, KINDS[kind], band, fields, threads, int(fill), C.byref(h))
+    if rc:
+        raise RuntimeError(f"scene generator failed (rc={rc}; more than 2^31 cells?)")
+    keep = _GenHandle(L, h)
+    nb, nc = L.exa_scenegen_num_bricks(h), L.exa_scenegen_num_cells(h)
+    hist = (C.c_uint64 * 8)()
+    L.exa_scenegen_level_histogram(h, hist)
+
+    def view(ptr, count, dtype):
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype)
+    bricks7 = view(L.exa_scenegen_bricks7(h), nb * 7, np.int32).reshape(-1, 7)
+    if not fill:
+        sc = Scene(bricks7.copy(), np.zeros(0, np.int32), [], name=name or kind)
+        sc.meta.update(num_cells=int(nc), levels_hist=list(hist)[:levels])
+        return sc
+    cellIDs = view(L.exa_scenegen_cell_ids(h), nc, np.int32)
+    flds = [view(L.exa_scenegen_field(h, f), nc, np.float32) for f in range(fields)]
+    sc = Scene(bricks7, cellIDs, flds, name=name or kind)
+    sc.value_range = (0.0, 1.0)
+    sc.meta.update(keep=keep, num_cells=int(nc), levels_hist=list(hist)[:levels], kind=kind, seed=seed,
+                   root=tuple(root), B=B, levels=levels, band=band)
+    return sc
+
+
+def config(name, scale=1.0, threads=0, fill=True):
+    """one of CONFIGS; scale < 1 shrinks the root grid (tests), keeping the feature."""
+    c = dict(CONFIGS[name])
+    root = tuple(max(1, int(round(r * scale))) for r in c.pop("root"))
+    kind = c.pop("kind")
+    return generated(kind=kind, root=root, threads=threads, fill=fill, name=name, **c)
