@@ -129,3 +129,40 @@ def write_png(path, rgba, flip=True):
     with open(path, "wb") as f:
         f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, 8, 6, 0, 0, 0))
                 + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+# ---- image-space sharding layout (host mirror of exa_hip_set_shard / exa_hip_untile) ----
+TILE = 16
+
+
+def shard_stride(W, H, world):
+    tiles = ((W + TILE - 1) // TILE) * ((H + TILE - 1) // TILE)
+    return ((tiles + world - 1) // world) * TILE * TILE
+
+
+def shard_from_image(img, rank, world):
+    """tile-major buffer of the 16x16 tiles t with t % world == rank (row-major tile order)."""
+    H, W = img.shape
+    tx, ty = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    out = np.zeros(shard_stride(W, H, world), dtype=img.dtype)
+    for t in range(rank, tx * ty, world):
+        x0, y0 = (t % tx) * TILE, (t // tx) * TILE
+        blk = np.zeros((TILE, TILE), dtype=img.dtype)
+        sub = img[y0:y0 + TILE, x0:x0 + TILE]
+        blk[:sub.shape[0], :sub.shape[1]] = sub
+        s = (t // world) * TILE * TILE
+        out[s:s + TILE * TILE] = blk.ravel()
+    return out
+
+
+def untile(gathered, W, H, world):
+    """inverse of shard_from_image over the concatenated shards of all ranks."""
+    stride = shard_stride(W, H, world)
+    tx, ty = (W + TILE - 1) // TILE, (H + TILE - 1) // TILE
+    img = np.zeros((H, W), dtype=gathered.dtype)
+    for t in range(tx * ty):
+        x0, y0 = (t % tx) * TILE, (t // tx) * TILE
+        s = (t % world) * stride + (t // world) * TILE * TILE
+        blk = gathered[s:s + TILE * TILE].reshape(TILE, TILE)
+        img[y0:y0 + TILE, x0:x0 + TILE] = blk[:min(TILE, H - y0), :min(TILE, W - x0)]
+    return img

@@ -1,0 +1,68 @@
+"""Regenerates tests/golden/ (run in the build container, where /root/reference exists).
+
+1. ref_artificial/exN.{cells,scalars}: OUTPUTS of the reference's own
+   tools/artificial generator (built by oracle/ref.mk into oracle/_ref/) on its own
+   ex0..ex4.grids inputs — data, not source.
+2. oracle_*.npz: frames rendered by the CPU oracle on those inputs (RGBA8, float accum,
+   work counters, region table).  The reference has no goldens of its own (no tests at
+   all), so these pin the oracle against regressions and pin the HIP path on the GPU box.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from common import Case, band_xf  # noqa: E402
+from owlexabrick_amd import scenes  # noqa: E402
+
+GOLDEN_CASES = {
+    # name: (scene, kwargs)
+    "ex0_dvr": ("ex0", dict(W=48, H=32)),
+    "ex1_grad": ("ex1", dict(W=48, H=32, grad=1)),
+    "ex2_dvr": ("ex2", dict(W=48, H=32)),
+    "ex2_grad_iso": ("ex2", dict(W=48, H=32, grad=1, iso=[(0.2, 0)])),
+    "ex3_dvr": ("ex3", dict(W=64, H=48)),
+    "ex3_grad": ("ex3", dict(W=64, H=48, grad=1)),
+    "ex3_iso": ("ex3", dict(W=64, H=48, grad=1, iso=[(0.4, 0)])),
+    "ex4_dvr_band": ("ex4", dict(W=64, H=48, xf="band")),
+    "ex4_grad_iso2": ("ex4", dict(W=64, H=48, grad=1, iso=[(0.3, 0), (0.7, 0)])),
+    "ex4_accum3": ("ex4", dict(W=64, H=48, grad=1, frames=3)),
+}
+
+
+def make_case(name):
+    scn, kw = GOLDEN_CASES[name]
+    kw = dict(kw)
+    frames = kw.pop("frames", 1)
+    if kw.get("xf") == "band":
+        kw["xf"] = band_xf()
+    return Case(scenes.example(scn), **kw), frames
+
+
+def main():
+    ref = os.path.join(ROOT, "oracle", "_ref", "exaArtificial")
+    if os.path.isdir("/root/reference"):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-f", "ref.mk", "-s"])
+        out = os.path.join(HERE, "ref_artificial")
+        os.makedirs(out, exist_ok=True)
+        for e in ("ex0", "ex1", "ex2", "ex3", "ex4"):
+            subprocess.check_call([ref, f"/root/reference/tools/artificial/{e}.grids", "-o", os.path.join(out, e)],
+                                  stdout=subprocess.DEVNULL)
+    for name in GOLDEN_CASES:
+        case, frames = make_case(name)
+        rgba, acc, st = case.run_oracle(nthreads=1, frames=frames)
+        S = case.oracle_scene()
+        np.savez_compressed(os.path.join(HERE, f"oracle_{name}.npz"), rgba=rgba, accum=acc,
+                            stats=np.array([st[k] for k in sorted(st)], dtype=np.int64),
+                            stat_keys=np.array(sorted(st)), regions=S.regions(), leaflist=S.leaflist())
+        print(name, st)
+
+
+if __name__ == "__main__":
+    main()

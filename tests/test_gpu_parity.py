@@ -1,0 +1,208 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle on
+identical inputs; against the committed goldens; and size-independent properties
+at the benchmark's frame size.  Tolerances are stated in tests/common.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from common import ACCUM_ATOL, Case, ROOT, band_xf, compare, po
+from owlexabrick_amd import binding, harness, scenes
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from make_golden import GOLDEN_CASES, make_case  # noqa: E402
+
+STAT_KEYS = ["segments", "sample_evals", "samples", "brick_visits", "corner_loads", "iso_segments", "iso_evals"]
+
+
+def _amr():
+    return scenes.amr(seed=3, root=(3, 3, 2), B=4, levels=3)
+
+
+CASES = {
+    "ex0": lambda: Case(scenes.example("ex0"), W=96, H=64),
+    "ex1_grad": lambda: Case(scenes.example("ex1"), W=96, H=64, grad=1),
+    "ex2": lambda: Case(scenes.example("ex2"), W=96, H=64),
+    "ex3": lambda: Case(scenes.example("ex3"), W=96, H=64),
+    "ex3_grad": lambda: Case(scenes.example("ex3"), W=96, H=64, grad=1),
+    "ex4_grad": lambda: Case(scenes.example("ex4"), W=96, H=64, grad=1),
+    "ex3_iso": lambda: Case(scenes.example("ex3"), W=96, H=64, grad=1, iso=[(0.4, 0)]),
+    "ex4_iso_noshade": lambda: Case(scenes.example("ex4"), W=96, H=64, iso=[(0.5, 0)], grad_iso=0),
+    "ex4_two_isos": lambda: Case(scenes.example("ex4"), W=96, H=64, grad=1, iso=[(0.3, 0), (0.7, 0)]),
+    "c1_64": lambda: Case(scenes.example("c1_64"), W=128, H=128),
+    "c1_64_grad_iso": lambda: Case(scenes.example("c1_64"), W=128, H=128, grad=1, iso=[(0.3, 0)]),
+    "amr": lambda: Case(_amr(), W=128, H=128),
+    "amr_grad": lambda: Case(_amr(), W=128, H=128, grad=1),
+    "amr_band": lambda: Case(_amr(), W=128, H=128, xf=band_xf()),
+    "amr_noskip": lambda: Case(_amr(), W=128, H=128, xf=band_xf(), space_skipping=0),
+    "amr_iso": lambda: Case(_amr(), W=128, H=128, grad=1, iso=[(0.45, 0)]),
+    "amr_clip": lambda: Case(_amr(), W=96, H=96, grad=1, clip=([10, 8, 4], [40, 40, 28])),
+    "amr_dt025_scale": lambda: Case(_amr(), W=96, H=96, dt=0.25, opacity_scale=0.3),
+    "amr_ragged": lambda: Case(_amr(), W=83, H=61, grad=1),                     # not a multiple of the tile
+    "amr_2ch": lambda: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2),
+                            W=128, H=128, grad=1),
+    "amr_2ch_colormap": lambda: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2),
+                                     W=96, H=96, grad=1, multi=False, iso=[(0.5, 0)]),
+    "amr_xfm": lambda: Case(_amr(), W=96, H=96, grad=1,
+                            xfm=dict(vx=[48, 0, 0], vy=[0, 48, 0], vz=[0, 0, 32], p=[0, 0, 0]),
+                            camera=([0.2, 1.7, 2.0], [0.5, 0.5, 0.5], [0, 1, 0], 60.0)),
+    "amr_inside": lambda: Case(_amr(), W=96, H=96, grad=1, camera=([20.3, 22.1, 14.2], [30, 20, 10], [0, 1, 0], 80.0)),
+    "gen_exajet": lambda: Case(scenes.generated(kind="exajet", seed=11, root=(4, 2, 2), B=8, levels=3), W=160, H=96, grad=1),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hip_matches_oracle(name):
+    case = CASES[name]()
+    o = case.run_oracle()
+    h = case.run_hip(stats=True)
+    r = compare(o, h, name)
+    assert r["accum_bad"] == 0 and r["rgba_bad"] == 0, r
+    assert {k: o[2][k] for k in STAT_KEYS} == {k: h[2][k] for k in STAT_KEYS}   # identical work, sample for sample
+
+
+def test_ao_rays_match_up_to_trig_ulps():
+    # AO directions go through cosf/sinf (libm vs OCML differ by an ulp); a hit/miss flip moves a
+    # pixel by 1/2 of its surface colour, so allow a handful of flipped pixels and nothing else
+    case = Case(scenes.example("ex4"), W=96, H=64, iso=[(0.5, 0)], ao=1, ao_length=3.0)
+    o, h = case.run_oracle(), case.run_hip()
+    da = np.abs(o[1] - h[1]).max(axis=-1)
+    assert (da > ACCUM_ATOL).sum() <= 0.002 * da.size
+    assert o[1][..., :3].sum() > 0
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
+def test_hip_matches_golden_fixture(name):
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"oracle_{name}.npz"))
+    case, frames = make_case(name)
+    rgba, acc, st = case.run_hip(frames=frames, stats=True)
+    assert np.abs(acc - g["accum"]).max() <= ACCUM_ATOL
+    d = np.abs(rgba.view(np.uint8).astype(int) - g["rgba"].view(np.uint8).astype(int))
+    assert d.max() <= 1
+    gs = dict(zip([str(k) for k in g["stat_keys"]], g["stats"].tolist()))
+    assert {k: gs[k] for k in STAT_KEYS} == {k: st[k] for k in STAT_KEYS}
+
+
+def test_region_activity_matches_bounds_programs():
+    case = Case(_amr(), W=32, H=32, xf=band_xf(), iso=[(0.45, 0)])
+    S = case.oracle_scene()
+    fs, P = case.oracle_state(S)
+    R = case.hip_renderer()
+    assert np.array_equal(R.readActivity(0), S.volume_active(fs, P))
+    assert np.array_equal(R.readActivity(1), S.iso_active(fs))
+    # updateXF re-evaluates activity (needVolumeBVHRebuild)
+    xf = harness.default_xf()
+    R.updateXF(0, xf[:, 3], xf[:, :3], case.xf_domains[0], 1.0)
+    S.set_xf(0, xf)
+    assert np.array_equal(R.readActivity(0), S.volume_active(fs, P))
+    R.setSpaceSkipping(False)
+    assert R.readActivity(0).all()
+    R.close()
+
+
+def test_state_changes_between_frames():
+    # one renderer, a sequence of setter calls as the viewer would issue them
+    case = Case(_amr(), W=64, H=64, grad=1)
+    R = case.hip_renderer()
+    img0 = R.render()
+    R.updateXF(0, band_xf()[:, 3], band_xf()[:, :3], case.xf_domains[0], 1.0)
+    img1 = R.render()
+    ref1 = Case(_amr(), W=64, H=64, grad=1, xf=band_xf()).run_oracle()
+    assert compare(ref1, (img1, R.readAccum(), None))["accum_bad"] == 0
+    R.updateIsoValues([0.45, 0], [0, 0], [1, 0])
+    img2 = R.render()
+    ref2 = Case(_amr(), W=64, H=64, grad=1, xf=band_xf(), iso=[(0.45, 0)]).run_oracle()
+    assert compare(ref2, (img2, R.readAccum(), None))["accum_bad"] == 0
+    R.updateIsoValues([0, 0], [0, 0], [0, 0])
+    R.resizeFrameBuffer((48, 32))
+    cam = harness.default_camera(*R.voxelSpaceBounds, 48, 32)
+    R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
+    img3 = R.render()
+    ref3 = Case(_amr(), W=48, H=32, grad=1, xf=band_xf()).run_oracle()
+    assert compare(ref3, (img3, R.readAccum(), None))["accum_bad"] == 0
+    assert not np.array_equal(img0[:32, :48], img3)
+    R.close()
+
+
+def test_progressive_accumulation_16_frames():
+    case = Case(scenes.example("ex4"), W=64, H=48, grad=1)
+    o = case.run_oracle(frames=16)
+    h = case.run_hip(frames=16)
+    r = compare(o, h)
+    assert np.abs(o[1] - h[1]).max() <= 16 * ACCUM_ATOL and r["rgba_bad"] == 0
+
+
+def test_tile_shards_and_untile_reassemble_frame():
+    import torch
+    case = Case(_amr(), W=104, H=72, grad=1)          # ragged tiles
+    full = case.run_hip()[0]
+    for world in (2, 3, 8):
+        stride = harness.shard_stride(104, 72, world)
+        gathered = torch.zeros(stride * world, dtype=torch.int32, device="cuda")
+        for rank in range(world):
+            R = case.hip_renderer()
+            R.setShard(rank, world)
+            R.updateFrameID(0)
+            shard = torch.zeros(stride, dtype=torch.int32, device="cuda")
+            R.render(device_ptr=shard.data_ptr())
+            gathered[rank * stride:(rank + 1) * stride] = shard
+            if rank == 0:
+                out = torch.zeros(104 * 72, dtype=torch.int32, device="cuda")
+                root = R
+            else:
+                R.close()
+        torch.cuda.synchronize()
+        root.untile(gathered.data_ptr(), stride, world, out.data_ptr())
+        torch.cuda.synchronize()
+        img = out.cpu().numpy().view(np.uint32).reshape(72, 104)
+        root.close()
+        assert np.array_equal(img, full), world
+        # the host mirror of the layout agrees with the device one
+        assert np.array_equal(harness.untile(gathered.cpu().numpy().view(np.uint32), 104, 72, world), full)
+
+
+def test_errors_are_reported_not_swallowed():
+    case = Case(scenes.example("ex2"), W=32, H=32)
+    R = case.hip_renderer()
+    R.params.numPrimaryChannels = 3                     # more channels than scalar fields
+    with pytest.raises(RuntimeError, match="channel counts"):
+        R.render()
+    R.params.numPrimaryChannels = 1
+    R.params.dt = 0.0
+    with pytest.raises(RuntimeError, match="dt must be"):
+        R.render()
+    R.params.dt = 0.5
+    with pytest.raises(RuntimeError, match="mismatching xf size"):
+        R.updateXF(0, np.zeros(10), np.zeros((10, 3)), (0, 1))
+    with pytest.raises(RuntimeError, match="bad size"):
+        R.resizeFrameBuffer((0, 5))
+    R.close()
+
+
+def test_full_frame_properties_at_benchmark_size():
+    """2048x2048 on an exajet-like scene: properties that do not need the oracle at full size,
+    plus an oracle check on a crop."""
+    sc = scenes.config("c4_exajet", scale=0.2)
+    case = Case(sc, W=2048, H=2048, grad=1, xf_domains=[(0.0, 1.0)])
+    R = case.hip_renderer()
+    R.setOption("tile_order", 0)
+    a = R.render()
+    R.setOption("tile_order", 1)
+    R.resizeFrameBuffer((2048, 2048))
+    b = R.render()
+    assert np.array_equal(a, b)                               # launch order never changes pixels
+    acc_skip = R.readAccum()
+    R.setSpaceSkipping(False)
+    c = R.render()
+    acc_noskip = R.readAccum()
+    assert np.abs(acc_skip - acc_noskip).max() < 1e-5         # KAT-7 at full size
+    assert np.abs(harness.unpack_rgba8(b).astype(int) - harness.unpack_rgba8(c).astype(int)).max() <= 1
+    R.close()
+    x0 = 1024 - 48
+    o = case.run_oracle(window=(x0, x0, x0 + 96, x0 + 96))
+    d = np.abs(o[1][x0:x0 + 96, x0:x0 + 96] - acc_skip[x0:x0 + 96, x0:x0 + 96])
+    assert d.max() <= ACCUM_ATOL + 1e-4 * np.abs(o[1]).max()
+    assert o[2]["samples"] > 0

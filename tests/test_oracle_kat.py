@@ -1,0 +1,200 @@
+"""Known-answer tests that pin the CPU oracle.
+Each expectation follows from the cited reference code, not from the oracle."""
+import numpy as np
+import pytest
+
+from common import Case, band_xf, po
+from owlexabrick_amd import harness, scenes
+
+f32 = np.float32
+
+
+def test_lcg_matches_published_algorithm():
+    # OWL LCG<16>: 16 TEA rounds on (seed0, seed1), then state = 1664525*state + 1013904223,
+    # value = (state & 0xFFFFFF) / 2^24 — restated independently in Python integers
+    def tea(v0, v1):
+        s0 = 0
+        M = 0xFFFFFFFF
+        for _ in range(16):
+            s0 = (s0 + 0x9E3779B9) & M
+            v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C) & M ^ ((v1 + s0) & M) ^ (((v1 >> 5) + 0xC8013EA4) & M))) & M
+            v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D) & M ^ ((v0 + s0) & M) ^ (((v0 >> 5) + 0x7E95761E) & M))) & M
+        return v0
+    for s0, s1 in [(0, 0), (1, 2), (123456, 77), (0xFFFFFFFF, 5)]:
+        st = tea(s0, s1)
+        exp = []
+        for _ in range(5):
+            st = (1664525 * st + 1013904223) & 0xFFFFFFFF
+            exp.append(np.float32((st & 0xFFFFFF) / float(1 << 24)))
+        got = po.lcg(s0, s1, 5)
+        assert np.array_equal(got, np.array(exp, dtype=np.float32))
+        assert (got >= 0).all() and (got < 1).all()
+
+
+def test_kat5_srgb_and_pack():
+    L = po.lib()
+    assert L.or_make_8bit(0.0) == 0 and L.or_make_8bit(1.0) == 255        # 256 clamps to 255
+    assert L.or_make_8bit(0.5) == 128 and L.or_make_8bit(-3.0) == 0
+    assert L.or_make_8bit(255.5 / 256) == 255 and L.or_make_8bit(0.999 / 256) == 0   # truncation, not rounding
+    assert L.or_linear_to_srgb(0.0) == 0.0
+    assert abs(L.or_linear_to_srgb(0.0031308) - 12.92 * 0.0031308) < 1e-7
+    assert abs(L.or_linear_to_srgb(1.0) - 1.0) < 1e-6
+    assert abs(L.or_linear_to_srgb(0.5) - (1.055 * 0.5 ** (1 / 2.4) - 0.055)) < 1e-6
+    assert L.or_make_rgba8(1.0, 0.5, 0.0) == (255 | (128 << 8) | (0 << 16) | (0xFF << 24))
+
+
+def test_box_test_semantics():
+    # strict t0 < t1, true division, axis-parallel rays (dir component 0 -> +-inf, ignored by fmin/fmax)
+    hit, t0, t1 = po.box_test([0, 0, -5], [0, 0, 1], 1e-6, 1e8, [-1, -1, -1], [1, 1, 1])
+    assert hit and t0 == 4 and t1 == 6
+    hit, _, _ = po.box_test([2, 0, -5], [0, 0, 1], 1e-6, 1e8, [-1, -1, -1], [1, 1, 1])
+    assert not hit
+    hit, t0, t1 = po.box_test([0, 0, 0], [0, 0, 1], 0.25, 0.5, [-1, -1, -1], [1, 1, 1])
+    assert hit and t0 == np.float32(0.25) and t1 == np.float32(0.5)
+    hit, _, _ = po.box_test([0, 0, -5], [0, 0, 1], 1e-6, 4.0, [-1, -1, -1], [1, 1, 1])
+    assert not hit            # t0 == t1 == 4 is not a hit
+
+
+def test_kat1_constant_field():
+    sc = scenes.example("ex0")               # one cell, value 1
+    S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    R = S.regions()
+    assert len(R) == 1 and np.allclose(R[0]["dom_lo"], -0.5) and np.allclose(R[0]["dom_hi"], 1.5)
+    rng = np.random.default_rng(0)
+    for p in rng.uniform(-0.45, 1.45, size=(50, 3)):
+        ok, v, _ = S.sample_point(0, p)
+        assert ok and v == np.float32(1.0)
+    ok, _, _ = S.sample_point(0, [5.0, 5.0, 5.0])      # far outside: weights 0 -> invalid
+    assert not ok
+
+
+def test_kat2_trilinear_interior_and_shell():
+    sc = scenes.example("ex2")               # 8^3, trilinear data
+    S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    vol = sc.fields[0].reshape(8, 8, 8)      # [z,y,x]
+    rng = np.random.default_rng(1)
+    for p in rng.uniform(0.5, 7.5, size=(100, 3)):
+        ok, v, g = S.sample_point(0, p, with_derivative=True)
+        q = p - 0.5
+        i = np.minimum(np.floor(q).astype(int), 6)
+        f = q - i
+        exp = 0.0
+        for dz in (0, 1):
+            for dy in (0, 1):
+                for dx in (0, 1):
+                    w = (f[0] if dx else 1 - f[0]) * (f[1] if dy else 1 - f[1]) * (f[2] if dz else 1 - f[2])
+                    exp += w * float(vol[i[2] + dz, i[1] + dy, i[0] + dx])
+        assert ok and abs(float(v) - exp) < 2e-6
+    # outer half-cell shell: partial weights, renormalised -> equals the nearest cell's value at a corner
+    ok, v, _ = S.sample_point(0, [-0.25, -0.25, -0.25])
+    assert ok and v == vol[0, 0, 0]
+    ok, v, _ = S.sample_point(0, [8.25, 8.25, 8.25])
+    assert ok and abs(float(v) - float(vol[7, 7, 7])) < 1e-7
+
+
+def _const_alpha_case(dt, a=0.05, W=24, H=16):
+    sc = scenes.artificial(scenes.parse_grids("0 0 0 16 16 16 0  0.5"))
+    xf = np.ones((128, 4), dtype=np.float32)
+    xf[:, 3] = a
+    return Case(sc, W=W, H=H, grad=0, xf=xf, dt=dt, xf_domains=[(0.0, 1.0)])
+
+
+def test_kat3_kat4_opacity_independent_of_dt_and_squared_alpha():
+    a = 0.05
+    imgs = {}
+    for dt in (1.0, 0.5, 0.25):
+        case = _const_alpha_case(dt, a)
+        imgs[dt] = case.run_oracle(nthreads=2)[1]
+    # path length L through the single region [-0.5,16.5]^3 for every pixel
+    case = _const_alpha_case(0.5, a)
+    S = case.oracle_scene()
+    lo, hi = S.voxel_bounds()
+    cam = case.cam(lo, hi)
+    for (px, py) in [(12, 8), (5, 3), (20, 12), (0, 0)]:
+        rnd = po.lcg(px, py, 2)
+        d = cam["dir00"] + f32(px + rnd[0]) * cam["dirDu"] + f32(py + rnd[1]) * cam["dirDv"]
+        d = d / np.linalg.norm(d)
+        hit, t0, t1 = po.box_test(cam["pos"], d, 1e-6, 1e8, [-0.5] * 3, [16.5] * 3)
+        L = float(t1 - t0) if hit else 0.0
+        A = 1.0 - (1.0 - a) ** L
+        A = min(A, 1.0)
+        for dt in imgs:
+            got = float(imgs[dt][py, px, 0])
+            if A < 0.97:
+                assert abs(got - A * A) < 2e-4, (px, py, dt, got, A * A)     # KAT-4: A^2 * c, c = 1
+    assert np.abs(imgs[1.0] - imgs[0.25])[..., :3].max() < 5e-4               # KAT-3
+
+
+def test_kat6_regions_partition_brick_domains():
+    for name in ("ex3", "ex4"):
+        sc = scenes.example(name)
+        S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+        R, LL = S.regions(), S.leaflist()
+        b = sc.bricks7.astype(np.float64)
+        cw = 2.0 ** b[:, 6]
+        dlo = b[:, 3:6] - 0.5 * cw[:, None]
+        dhi = b[:, 3:6] + (b[:, 0:3] + 0.5) * cw[:, None]
+        rng = np.random.default_rng(7)
+        pts = rng.uniform(dlo.min(axis=0), dhi.max(axis=0), size=(3000, 3))
+        for p in pts:
+            bricks = set(np.nonzero(((p > dlo) & (p < dhi)).all(axis=1))[0].tolist())
+            inside = np.nonzero(((p > R["dom_lo"]) & (p < R["dom_hi"])).all(axis=1))[0]
+            if not bricks:
+                assert len(inside) == 0
+                continue
+            if len(inside) == 0:       # exactly on a face
+                continue
+            assert len(inside) == 1                                   # disjoint
+            r = R[inside[0]]
+            got = set(LL[r["leafListBegin"]:r["leafListBegin"] + r["leafListSize"]].tolist())
+            assert got == bricks                                      # the set of overlapping basis domains
+        vol_regions = np.prod(R["dom_hi"].astype(np.float64) - R["dom_lo"], axis=1).sum()
+        frac_inside = np.mean([((p > dlo) & (p < dhi)).all(axis=1).any() for p in pts])
+        vol_box = np.prod(dhi.max(axis=0) - dlo.min(axis=0))
+        assert abs(vol_regions / vol_box - frac_inside) < 0.03        # union of regions == union of domains
+        # finest level per region = min level of its bricks (Regions.cpp:293-299)
+        for r in R:
+            ids = LL[r["leafListBegin"]:r["leafListBegin"] + r["leafListSize"]]
+            assert r["finestLevelCellWidth"] == 2.0 ** sc.bricks7[ids, 6].min()
+            assert list(ids) == sorted(set(ids.tolist()))            # std::set order
+
+
+def test_kat7_space_skipping_is_image_neutral():
+    sc = scenes.amr(seed=3, root=(2, 2, 2), B=4, levels=3)
+    on = Case(sc, W=48, H=48, xf=band_xf(), space_skipping=1).run_oracle()
+    off = Case(sc, W=48, H=48, xf=band_xf(), space_skipping=0).run_oracle()
+    assert on[2]["samples"] < off[2]["samples"]                      # skipping really skips
+    assert np.abs(on[1] - off[1]).max() < 1e-5
+    d = np.abs(harness.unpack_rgba8(on[0]).astype(int) - harness.unpack_rgba8(off[0]).astype(int))
+    assert d.max() <= 1
+
+
+def test_kat8_iso_crossing_resamples_at_iso_value():
+    # field = x/8 (linear along x); grey-ramp colour so the pixel decodes the value at the hit point
+    sc = scenes.artificial(scenes.parse_grids("0 0 0 8 8 8 0  0 1 0 1 0 1 0 1"))
+    xf = np.zeros((128, 4), dtype=np.float32)
+    xf[:, 0] = np.arange(128) / 127.0          # r = value, alpha 0: no DVR contribution
+    for iso in (0.3, 0.5, 0.62):
+        case = Case(sc, W=16, H=16, grad=0, grad_iso=0, iso=[(iso, 0)], xf=xf, xf_domains=[(0.0, 1.0)],
+                    camera=([-10, 4.1, 4.2], [4, 4, 4], [0, 1, 0], 20.0))
+        rgba, acc, st = case.run_oracle(nthreads=1)
+        assert st["iso_segments"] > 0
+        centre = acc[6:10, 6:10, 0]
+        assert np.abs(centre - iso).max() < 0.01, (iso, centre)
+
+
+def test_trace_region_kd_equals_brute_force():
+    sc = scenes.amr(seed=9, root=(2, 2, 1), B=4, levels=3)
+    S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    rng = np.random.default_rng(3)
+    lo, hi = S.voxel_bounds()
+    active = (rng.uniform(size=S.num_regions) < 0.6).astype(np.uint8)
+    for _ in range(400):
+        o = rng.uniform(lo - 10, hi + 10)
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        if rng.uniform() < 0.2:
+            d[rng.integers(3)] = 0.0            # axis-parallel components
+            d /= np.linalg.norm(d)
+        r, t0, t1 = S.trace_region(active, o, d, 1e-6, 1e8)
+        assert r != -2                           # kd-pruned search == brute force
