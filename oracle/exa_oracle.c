@@ -364,6 +364,17 @@ void or_set_xf(OrScene *S, int chan, const float *rgba128)
 /* ------------------------------------------------------------------ */
 /* pixel helpers                                                       */
 /* ------------------------------------------------------------------ */
+/* float -> int as the device does it (CUDA cvt.rzi.s32.f32 and gfx950 v_cvt_i32_f32
+ * alike): truncate, saturate, NaN -> 0.  A plain C cast is undefined for those inputs
+ * and x86 returns INT_MIN; the reference only ever runs this code on the GPU. */
+static inline int f2i(float f)
+{
+  if (f != f) return 0;
+  if (f >= 2147483648.f) return 2147483647;
+  if (f <= -2147483648.f) return (-2147483647 - 1);
+  return (int)f;
+}
+
 /* exabrick.cu:53-60 */
 float or_linear_to_srgb(float x)
 {
@@ -373,7 +384,7 @@ float or_linear_to_srgb(float x)
 /* exabrick.cu:62-66 */
 int32_t or_make_8bit(float f)
 {
-  int v = (int)(f * 256.f);
+  int v = f2i(f * 256.f);
   v = v > 0 ? v : 0;
   return v < 255 ? v : 255;
 }
@@ -397,8 +408,8 @@ static inline v4 tex1d_linear(const float (*T)[4], float u)
   float x = u * (float)OR_NUM_XF_VALUES - 0.5f;
   float fl = floorf(x);
   float a = x - fl;
-  int i0 = clampi((int)fl, 0, OR_NUM_XF_VALUES - 1);
-  int i1 = clampi((int)fl + 1, 0, OR_NUM_XF_VALUES - 1);
+  int i0 = clampi(f2i(fl), 0, OR_NUM_XF_VALUES - 1);
+  int i1 = clampi(f2i(fl) + 1, 0, OR_NUM_XF_VALUES - 1);
   float na = 1.f - a;
   v4 r;
   r.x = na * T[i0][0] + a * T[i1][0];
@@ -448,8 +459,8 @@ static int active_for_volume_sampling(const OrScene *S, const OrFrameState *fs,
   if (vhi < dlo) return 0;
   const float scaled_lo = (vlo - dlo) / ((dhi - dlo) + 1e-20f);
   const float scaled_hi = (vhi - dlo) / ((dhi - dlo) + 1e-20f);
-  const int idx_lo = clampi((int)(scaled_lo * (OR_NUM_XF_VALUES - 1)), 0, OR_NUM_XF_VALUES - 1);
-  const int idx_hi = clampi((int)(scaled_hi * (OR_NUM_XF_VALUES - 1)) + 1, 0, OR_NUM_XF_VALUES - 1);
+  const int idx_lo = clampi(f2i(scaled_lo * (OR_NUM_XF_VALUES - 1)), 0, OR_NUM_XF_VALUES - 1);
+  const int idx_hi = clampi(f2i(scaled_hi * (OR_NUM_XF_VALUES - 1)) + 1, 0, OR_NUM_XF_VALUES - 1);
   for (int i = idx_lo; i <= idx_hi; i++) {
     float cellValue = (float)i / (OR_NUM_XF_VALUES - 1);
     cellValue *= dhi - dlo;
@@ -601,7 +612,7 @@ static void add_basis_functions(Ctx *C, Basis *B, int need_derivative, int brick
 
   const v3 lower = V3((float)brick->lower[0], (float)brick->lower[1], (float)brick->lower[2]);
   const v3 localPos = vsub(vdiv(vsub(pos, lower), v3s(cellWidth)), v3s(0.5f));
-  int lx = (int)floorf(localPos.x), ly = (int)floorf(localPos.y), lz = (int)floorf(localPos.z);
+  int lx = f2i(floorf(localPos.x)), ly = f2i(floorf(localPos.y)), lz = f2i(floorf(localPos.z));
   lx = lx > -1 ? lx : -1; ly = ly > -1 ? ly : -1; lz = lz > -1 ? lz : -1;   /* max(vec3i(-1),idx_lo) */
   const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
   const v3 frac = vsub(localPos, V3((float)lx, (float)ly, (float)lz));
@@ -775,7 +786,7 @@ static void iso_func_call(Ctx *C, IsoFunc *F, const Ray *ray, IntegrationResult 
 /* first sample position, exabrick.cu:1141-1144 */
 static inline float first_t(float t0, float dt, float off)
 {
-  int i0 = (int)ceilf((t0 - dt * off) / dt);
+  int i0 = f2i(ceilf((t0 - dt * off) / dt));
   float t_i = (off + i0) * dt;
   while ((t_i - dt) >= t0) t_i = t_i - dt;
   while (t_i < t0) t_i += dt;
@@ -788,7 +799,7 @@ static void integrate_brick(Ctx *C, int gradient_shading, IntegrationResult *res
 {
   const OrRegion *region = &C->S->regions[leafID];
   const float dt = C->P->dt * region->finestLevelCellWidth;
-  const int finestLevelCellWidth = (int)region->finestLevelCellWidth;
+  const int finestLevelCellWidth = f2i(region->finestLevelCellWidth);
   float t_i = first_t(t0, dt, off);
   float t_last = t0;
   for (;; t_i += dt) {

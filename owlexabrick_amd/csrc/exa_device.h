@@ -60,6 +60,7 @@ struct RenderArgs {
   float4            *accum;
   unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
   int32_t           *errorFlag;     // set when a loop guard trips
+  int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
 };
 
 // ---- launchers implemented in exa_kernels.hip ----

@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
   const int px = tx * kTile + inX, py = ty * kTile + inY;
-  const bool inside = px < a.W && py < a.H;
+  const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
 
   if (inside) {
     const ExaHipFrameState &fs = a.fs;

@@ -179,6 +179,7 @@ struct ExaHipRenderer {
   int W = 0, H = 0, tilesX = 0, tilesY = 0;
   int rank = 0, world = 1;
   int tileOrder = 0;
+  int debugPixel = -1;
   DevBuf<float4> accum;
   DevBuf<uint32_t> color;
   DevBuf<int32_t> tileMap;
@@ -293,6 +294,7 @@ struct ExaHipRenderer {
     a.accum = accum.p;
     a.stats = statsBuf.p;
     a.errorFlag = errorFlag.p;
+    a.debugPixel = debugPixel;
     HIP_TRY(this, hipEventRecord(ev0, s));
     HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, isoEnabled(), stats, s));
     HIP_TRY(this, hipEventRecord(ev1, s));
@@ -479,6 +481,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
 {
   if (!h || !key) return 1;
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
+  if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   h->fail(std::string("exa_hip_set_option: unknown key ") + key);
   return 1;
 }
