@@ -77,6 +77,19 @@ typedef struct ExaHipParams {
   int32_t spaceSkippingEnabled; /* !contourPlanesActive && doSpaceSkipping (OptixRenderer.cpp:418-432) */
 } ExaHipParams;
 
+/* The recursion of ExaBrickRegions::buildRec (exa/Regions.cpp:73-179) is a kd-tree
+ * whose leaves are the regions; exa_prep keeps it.  A child reference is >= 0 for a
+ * node index, < 0 for a leaf (region id = ~ref), EXA_KD_EMPTY for an empty side.
+ * Optional input of exa_hip_create: with it the module walks the regions in exact
+ * front-to-back order; without it (regions built elsewhere) it uses its LBVH. */
+#define EXA_KD_EMPTY INT32_MIN
+typedef struct ExaKdNode {
+  float   split;   /* plane position on `axis`                         */
+  int32_t axis;    /* 0,1,2                                            */
+  int32_t left;    /* child on the lower side of the plane             */
+  int32_t right;   /* child on the upper side                          */
+} ExaKdNode;
+
 /* what the OptixRenderer constructor uploads (OptixRenderer.cpp:95-98,133-141,160-168) */
 typedef struct ExaHipScene {
   const ExaBrick       *bricks;        uint64_t numBricks;
@@ -87,6 +100,9 @@ typedef struct ExaHipScene {
   uint64_t              totalCells;
   int32_t               numFields;
   float                 voxelBounds_lo[3], voxelBounds_hi[3];
+  const ExaKdNode      *kdNodes;       /* optional (may be NULL) */
+  uint64_t              numKdNodes;
+  int32_t               kdRoot;        /* reference of the root (a leaf ref for a one-region scene) */
 } ExaHipScene;
 
 /* work counters of one frame (instrumented kernel variant); the basis of the
@@ -99,7 +115,9 @@ typedef struct ExaHipStats {
   uint64_t corner_loads;  /* cell scalars read, all paths                          */
   uint64_t iso_segments;  /* iso-BVH hits                                          */
   uint64_t iso_evals;     /* sample calls of the iso march (+ re-samples)          */
-  uint64_t nodes_visited; /* LBVH nodes fetched (64 B each), both BVHs             */
+  uint64_t nodes_visited; /* acceleration-structure nodes fetched: 64-B LBVH nodes or
+                             16-B kd nodes, see node_bytes                         */
+  uint64_t node_bytes;    /* bytes per node of the structure that was walked       */
   uint64_t pixels;        /* pixels rendered by this handle (its tile shard)       */
   float    kernel_ms;     /* hipEvent time of the last render launch               */
   float    rebuild_ms;    /* hipEvent time of the last activity+refit pass         */
@@ -192,7 +210,8 @@ int exa_hip_write_accum(ExaHipRenderer *, const float *src4);
 int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, uint8_t *dst);
 
 /* tuning knobs that never change results: "tile_order" 0 = row-major tile launch
- * order, 1 = XCD-aware supertile order */
+ * order, 1 = XCD-aware supertile order; "accel" 0 = LBVH with restart per segment,
+ * 1 = region kd-tree walked front to back (default when the scene carries one) */
 int exa_hip_set_option(ExaHipRenderer *, const char *key, int32_t value);
 
 const char *exa_hip_last_error(const ExaHipRenderer * /* may be NULL: creation errors */);

@@ -55,12 +55,13 @@ class ExaHipScene(C.Structure):
                 ("leafList", C.c_void_p), ("leafListSize", C.c_uint64),
                 ("scalars", C.c_void_p), ("channelOffset", C.c_void_p),
                 ("totalCells", C.c_uint64), ("numFields", C.c_int32),
-                ("voxelBounds_lo", C.c_float * 3), ("voxelBounds_hi", C.c_float * 3)]
+                ("voxelBounds_lo", C.c_float * 3), ("voxelBounds_hi", C.c_float * 3),
+                ("kdNodes", C.c_void_p), ("numKdNodes", C.c_uint64), ("kdRoot", C.c_int32)]
 
 
 class ExaHipStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("segments", "sample_evals", "samples", "brick_visits", "corner_loads",
-                                          "iso_segments", "iso_evals", "nodes_visited", "pixels")] + \
+                                          "iso_segments", "iso_evals", "nodes_visited", "node_bytes", "pixels")] + \
                [("kernel_ms", C.c_float), ("rebuild_ms", C.c_float)]
 
     def asdict(self):
@@ -70,6 +71,8 @@ class ExaHipStats(C.Structure):
 BRICK_DTYPE = np.dtype([("lower", "<i4", 3), ("size", "<i4", 3), ("level", "<i4"), ("begin", "<u4")])
 REGION_DTYPE = np.dtype([("dom_lo", "<f4", 3), ("dom_hi", "<f4", 3), ("vr_lo", "<f4"), ("vr_hi", "<f4"),
                          ("leafListBegin", "<i4"), ("leafListSize", "<i4"), ("finestLevelCellWidth", "<f4")])
+KDNODE_DTYPE = np.dtype([("split", "<f4"), ("axis", "<i4"), ("left", "<i4"), ("right", "<i4")])
+KD_EMPTY = -2 ** 31
 
 # every symbol include/exa_hip.h declares
 ABI_SYMBOLS = ["exa_prep_create", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error",
@@ -158,6 +161,9 @@ class Prep:
 
     def scalars(self):
         return self._arr(self.scene.scalars, self.scene.numFields * self.scene.totalCells, np.float32)
+
+    def kd_nodes(self):
+        return self._arr(self.scene.kdNodes, self.scene.numKdNodes, KDNODE_DTYPE)
 
     def voxel_bounds(self):
         return (np.array(self.scene.voxelBounds_lo, dtype=np.float32),

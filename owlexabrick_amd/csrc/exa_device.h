@@ -28,6 +28,25 @@ struct alignas(16) RegionInfo {
   int32_t firstBrick;     // leafList[listBegin], saves a dependent load
 };
 
+// kd node of the region partition (16 B, one load): the split plane and, refreshed by
+// the refit pass, which children hold an active region.
+//   word: bits 0-1 axis | bit 2 left active (volume) | bit 3 right active (volume)
+//                       | bit 4 left active (iso)    | bit 5 right active (iso)
+struct alignas(16) KdNodeDev {
+  float    split;
+  uint32_t word;
+  int32_t  left, right;     // >= 0 node, < 0 leaf (~region), EXA_KD_EMPTY nothing
+};
+static_assert(sizeof(KdNodeDev) == 16, "kd node = one 16-byte load");
+
+// region record of the kd path: exact domain for the slab test plus the march data (48 B)
+struct alignas(16) RegionRec {
+  float   lo[3], hi0;       // domain lower, domain upper.x
+  float   hi1, hi2, finestLevelCellWidth; int32_t firstBrick;
+  int32_t listBegin, listSize, pad0, pad1;
+};
+static_assert(sizeof(RegionRec) == 48, "region record = three 16-byte loads");
+
 struct DeviceScene {
   const int4       *bricks;        // ExaBrick as two int4: (lower.xyz,size.x) (size.yz,level,begin)
   const int32_t    *leafList;
@@ -40,7 +59,7 @@ struct DeviceScene {
   uint32_t numInternal;            // internal LBVH nodes
 };
 
-enum { kTile = 16, kTilePixels = 256, kStackDepth = 32 };
+enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 12 };
 
 enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CORNER_LOADS,
                 ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES, ST_COUNT };
@@ -49,6 +68,10 @@ struct RenderArgs {
   DeviceScene        sc;
   const BvhNode     *volNodes;
   const BvhNode     *isoNodes;
+  const KdNodeDev   *kdNodes;       // region kd-tree (NULL: LBVH only)
+  const RegionRec   *regionRec;
+  int32_t            kdRoot;
+  float              kdLo[3], kdHi[3];   // box of the kd root = union of all brick domains
   ExaHipFrameState   fs;
   ExaHipParams       p;
   const float4      *xf;            // numXfChannels x 128 (r,g,b,a)
@@ -71,6 +94,9 @@ hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, 
 // refit one height class of internal nodes: box of each child = union below it
 hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
                        const uint8_t *active, hipStream_t s);
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool stats, hipStream_t s);
+// kd activity bits of one height class; which = 0 volume, 1 iso
+hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,
                         int W, int H, uint32_t *out, hipStream_t s);
 

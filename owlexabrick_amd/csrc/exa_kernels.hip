@@ -645,6 +645,341 @@ hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso,
   return hipGetLastError();
 }
 
+// ========================================================================
+// v2: region kd-tree walked front to back + flattened march.
+//
+// The recursion of ExaBrickRegions::buildRec is a kd-tree whose leaves are the
+// regions, so the regions a ray crosses come out of one ordered walk: no restart
+// per segment (exabrick.cu:1675-1699 re-traces the BVH for every region) and one
+// 16-byte node + one division per step instead of a 64-byte node + 12 divisions.
+// Every visited leaf still gets the reference's exact slab test against its
+// domain with the current ray.tmin, so accepted segments [t0,t1] are the ones
+// the closest-hit search returns (disjoint boxes: the first accepted leaf in
+// front-to-back order is the one with the smallest clamped t0).
+//
+// The march itself is one loop whose unit of work is ONE brick visit
+// (addBasisFunctions).  Lanes of a wave sit in regions with different brick
+// counts k and different segment lengths; with nested loops a wave runs at the
+// pace of its slowest lane in every loop level, flattened it only idles in the
+// short per-sample epilogue.  Per-sample arithmetic and its order are unchanged.
+// ========================================================================
+struct KdWalk {
+  int   ref;            // current subtree reference, or KD_DONE
+  float tn, tf;         // its interval along the ray
+  int   head, count;    // short stack (circular, in LDS)
+  bool  dropped;        // an entry fell off the bottom: restart from the root when empty
+  float tEnd;           // end of the root interval
+};
+#define EXA_KD_DONE (EXA_KD_EMPTY + 1)
+
+template <bool STATS>
+__device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs &a, float *stackF)
+{
+  if (w.count > 0) {
+    w.head = w.head == 0 ? kKdStack - 1 : w.head - 1;
+    w.count--;
+    w.ref = C.stack[w.head * 256];
+    w.tn = stackF[(2 * w.head) * 256];
+    w.tf = stackF[(2 * w.head + 1) * 256];
+  } else if (w.dropped && w.tf < w.tEnd) {
+    w.ref = a.kdRoot;                  // short-stack restart: everything before tf is done
+    w.tn = w.tf;
+    w.tf = w.tEnd;
+    w.dropped = false;
+  } else {
+    w.ref = EXA_KD_DONE;
+  }
+}
+
+// advance to the next leaf whose subtree is active; returns the region id or -1
+template <bool STATS>
+__device__ __forceinline__ int kdNextLeaf(Ctx<STATS> &C, KdWalk &w, const RenderArgs &a, float *stackF,
+                                          const V3 org, const V3 dir, const int which, const float tminCur)
+{
+  for (;;) {
+    if (w.ref == EXA_KD_DONE) return -1;
+    if (w.ref == EXA_KD_EMPTY || !(w.tf > tminCur)) { kdPop(C, w, a, stackF); continue; }
+    if (w.ref < 0) {                               // leaf: hand it out, then continue with the stack
+      const int region = ~w.ref;
+      w.ref = EXA_KD_EMPTY;
+      return region;
+    }
+    const int4 n = *reinterpret_cast<const int4 *>(a.kdNodes + w.ref);
+    C.count(ST_NODES);
+    const float split = __int_as_float(n.x);
+    const int axis = n.y & 3;
+    const int bits = (n.y >> (2 + 2 * which)) & 3;          // bit0 left active, bit1 right active
+    const float o = axis == 0 ? org.x : (axis == 1 ? org.y : org.z);
+    const float d = axis == 0 ? dir.x : (axis == 1 ? dir.y : dir.z);
+    if (d == 0.f) {
+      // parallel to the plane: only the side that strictly contains the origin can be hit
+      // (boxTest turns lo==o / hi==o into a miss, see exabrick.cu:201-208 with NaN-ignoring min/max)
+      if (o < split && (bits & 1)) w.ref = n.z;
+      else if (o > split && (bits & 2)) w.ref = n.w;
+      else kdPop(C, w, a, stackF);
+      continue;
+    }
+    const float ts = (split - o) / d;                       // same expression as the slab test
+    const bool nearIsLeft = d > 0.f;
+    const int nearRef = nearIsLeft ? n.z : n.w, farRef = nearIsLeft ? n.w : n.z;
+    const bool nearAct = (bits & (nearIsLeft ? 1 : 2)) != 0, farAct = (bits & (nearIsLeft ? 2 : 1)) != 0;
+    if (ts >= w.tf) {                                        // plane behind the interval: near side only
+      if (nearAct) w.ref = nearRef; else kdPop(C, w, a, stackF);
+    } else if (ts <= w.tn) {                                 // plane before the interval: far side only
+      if (farAct) w.ref = farRef; else kdPop(C, w, a, stackF);
+    } else if (nearAct) {
+      if (farAct) {                                          // push far [ts,tf], go near [tn,ts]
+        C.stack[w.head * 256] = farRef;
+        stackF[(2 * w.head) * 256] = ts;
+        stackF[(2 * w.head + 1) * 256] = w.tf;
+        w.head = w.head == kKdStack - 1 ? 0 : w.head + 1;
+        if (w.count == kKdStack) w.dropped = true; else w.count++;
+      }
+      w.ref = nearRef;
+      w.tf = ts;
+    } else if (farAct) {
+      w.ref = farRef;
+      w.tn = ts;
+    } else {
+      kdPop(C, w, a, stackF);
+    }
+  }
+}
+
+template <bool GRAD, bool STATS>
+__global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *xfLds = reinterpret_cast<float4 *>(smem);
+  unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
+  int *stackRef = reinterpret_cast<int *>(sp0);
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * 256 * sizeof(int)) + threadIdx.x;
+  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += 256) xfLds[i] = a.xf[i];
+  __syncthreads();
+
+  Ctx<STATS> C;
+  C.a = &a;
+  C.xfLds = xfLds;
+  C.stack = stackRef + threadIdx.x;
+  C.guardTripped = false;
+  if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
+
+  const int tile = a.tileMap[blockIdx.x];
+  const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
+  const int px = tx * kTile + inX, py = ty * kTile + inY;
+  const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
+
+  if (inside) {
+    const ExaHipFrameState &fs = a.fs;
+    const int frameID = fs.frameID;
+    Lcg rnd;
+    rnd.init((uint32_t)(frameID * a.W * a.H) + (uint32_t)px, (uint32_t)py);      // :1591-1592
+    const float sx = float(px) + rnd.next();
+    const float sy = float(py) + rnd.next();
+    Ray ray;
+    ray.org = mk(fs.cam_pos);
+    ray.dir = normalize((mk(fs.cam_dir00) + sx * mk(fs.cam_dirDu)) + sy * mk(fs.cam_dirDv));
+    ray.tmin = 1e-6f; ray.tmax = 1e8f;
+    const float interleavedSamplingOffset = rnd.next();                           // :1655 (no surfaces: 3rd draw)
+    float surface_t_hit = ray.tmax;                                               // :1657-1659
+    if (fs.clipBox.enabled) {
+      float c0, c1;
+      boxTest(ray, mk(fs.clipBox.lo), mk(fs.clipBox.hi), c0, c1);
+      ray.tmin = c0; ray.tmax = c1;
+    }
+    surface_t_hit = ray.tmax;
+    ray.org = xfmPoint(fs, ray.org);                                              // :1664-1668
+    ray.dir = xfmVector(fs, ray.dir);
+    const float dt_scale = length(ray.dir);
+    ray.dir = normalize(ray.dir);
+    ray.tmin = dt_scale * ray.tmin;                                               // alreadyIntegratedDistance
+    ray.tmax = surface_t_hit * dt_scale;
+
+    Color4 pixelColor; pixelColor.x = pixelColor.y = pixelColor.z = pixelColor.w = 0.f;
+    const int numChannels = a.p.numPrimaryChannels;
+
+    // ---- walk set-up: interval of the kd root along the ray ----
+    KdWalk w;
+    w.head = 0; w.count = 0; w.dropped = false;
+    {
+      Ray whole = ray; whole.tmin = -INFINITY; whole.tmax = INFINITY;
+      float r0, r1;
+      const bool hit = boxTest(whole, mk(a.kdLo), mk(a.kdHi), r0, r1);
+      w.tn = fmaxf(r0, ray.tmin);
+      w.tf = fminf(r1, ray.tmax);
+      w.tEnd = w.tf;
+      w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
+    }
+
+    // ---- segment / sample state ----
+    bool haveSeg = false;
+    int listBegin = 0, listSize = 0, firstBrick = 0, finestLevelCellWidth = 1;
+    float dt = 0.f, t1 = 0.f, t_i = 0.f, t_last = 0.f, t_next = 0.f, actual_dt = 0.f;
+    V3 pos = mk(0.f, 0.f, 0.f);
+    int child = 0, chan = 0, brickID = 0, loadedBrick = -1;
+    int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 0, 0);
+    Basis B;
+    B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+    const float *field = a.sc.scalars + a.sc.channelOffset[0];
+
+    for (unsigned iter = 0;; iter++) {
+      if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
+      if (!haveSeg) {
+        // ---- next segment: first leaf in front-to-back order that passes the slab test ----
+        float t0 = 0.f;
+        bool found = false;
+        for (;;) {
+          const int region = kdNextLeaf(C, w, a, stackF, ray.org, ray.dir, 0, ray.tmin);
+          if (region < 0) break;
+          const float4 *rp = reinterpret_cast<const float4 *>(a.regionRec + region);
+          const float4 r0 = rp[0], r1 = rp[1];
+          if (boxTest(ray, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), t0, t1)) {   // exabrick.cu:213-238
+            const int4 r2 = *reinterpret_cast<const int4 *>(rp + 2);
+            listBegin = r2.x; listSize = r2.y;
+            firstBrick = __float_as_int(r1.w);
+            finestLevelCellWidth = (int)r1.z;
+            dt = a.p.dt * r1.z;                                                    // :1129
+            found = true;
+            break;
+          }
+        }
+        if (!found) break;
+        C.count(ST_SEGMENTS);
+        haveSeg = true;
+        t_i = firstSampleT(t0, dt, interleavedSamplingOffset);                     // :1141-1144
+        t_last = t0;
+        // first step of the segment (:1158-1166)
+        t_next = fminf(t_i, t1);
+        const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
+        actual_dt = t_next - t_last;
+        t_last = t_next;
+        pos = ray.org + t_sample * ray.dir;
+        child = 0; chan = 0; brickID = firstBrick;
+        field = a.sc.scalars + a.sc.channelOffset[0];
+        B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+        C.count(ST_SAMPLE_EVALS);
+      }
+
+      // ---- one brick visit ----
+      if (brickID != loadedBrick) {
+        hb0 = a.sc.bricks[2 * brickID]; hb1 = a.sc.bricks[2 * brickID + 1];
+        loadedBrick = brickID;
+      }
+      addBasisFunctions<GRAD, STATS>(C, B, hb0, hb1, field, pos);
+      child++;
+      if (child < listSize) { brickID = a.sc.leafList[listBegin + child]; continue; }
+
+      // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
+      if (B.sumW > 1e-20f) {
+        C.count(ST_SAMPLES);
+        const float cellValue = B.sumWV / B.sumW;
+        V3 grad = mk(0.f, 0.f, 0.f);
+        if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
+                            B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
+                            B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
+        integrateVolume(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, chan);
+      }
+      chan++;
+      B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+      child = 0; brickID = firstBrick;
+      if (chan < numChannels) {
+        field = a.sc.scalars + a.sc.channelOffset[chan];
+        C.count(ST_SAMPLE_EVALS);
+        continue;
+      }
+      // ---- end of this step (:1180-1183) ----
+      if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) {
+        pixelColor.x = pixelColor.x * pixelColor.w;                                // :1694-1696
+        pixelColor.y = pixelColor.y * pixelColor.w;
+        pixelColor.z = pixelColor.z * pixelColor.w;
+        pixelColor.w = 1.f;
+        break;
+      }
+      if (t_next >= t1) {                                                          // segment done
+        ray.tmin = t1 * (1.0000001f);                                              // :1698
+        haveSeg = false;
+        continue;
+      }
+      t_i += dt;
+      t_next = fminf(t_i, t1);
+      {
+        const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
+        actual_dt = t_next - t_last;
+        t_last = t_next;
+        pos = ray.org + t_sample * ray.dir;
+      }
+      chan = 0;
+      field = a.sc.scalars + a.sc.channelOffset[0];
+      C.count(ST_SAMPLE_EVALS);
+    }
+
+    float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * 0.f;           // :1701, bgColor = 0
+    float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * 0.f;
+    float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * 0.f;
+    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
+                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+    if (frameID > 0) {
+      const float4 acc = a.accum[slot];
+      cr += acc.x; cg += acc.y; cb += acc.z;
+    }
+    a.accum[slot] = make_float4(cr, cg, cb, 1.f);
+    const float div = frameID + 1.f;
+    cr = cr / div; cg = cg / div; cb = cb / div;
+    a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+  }
+
+  if (C.guardTripped) atomicExch(a.errorFlag, 1);
+  if (STATS) {
+    for (int i = 0; i < ST_COUNT; i++) {
+      unsigned long long v = inside ? C.st[i] : 0ull;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.stats[i], v);
+    }
+  }
+}
+
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool stats, hipStream_t s)
+{
+  if (numBlocks <= 0) return hipSuccess;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack) * 256 * 12;
+  const dim3 grid(numBlocks), block(256);
+  if (stats) {
+    if (grad) hipLaunchKernelGGL((renderFrameKdKernel<true, true>), grid, block, lds, s, a);
+    else      hipLaunchKernelGGL((renderFrameKdKernel<false, true>), grid, block, lds, s, a);
+  } else {
+    if (grad) hipLaunchKernelGGL((renderFrameKdKernel<true, false>), grid, block, lds, s, a);
+    else      hipLaunchKernelGGL((renderFrameKdKernel<false, false>), grid, block, lds, s, a);
+  }
+  return hipGetLastError();
+}
+
+// kd activity bits, one height class per launch (children before parents)
+__global__ __launch_bounds__(256) void kdRefitKernel(KdNodeDev *nodes, const int32_t *nodeIds, int count,
+                                                     const uint8_t *active, int which)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  const int id = nodeIds[i];
+  const KdNodeDev n = nodes[id];
+  const int sh = 2 + 2 * which;
+  auto act = [&](int ref) -> uint32_t {
+    if (ref == EXA_KD_EMPTY) return 0u;
+    if (ref < 0) return active[~ref] ? 1u : 0u;
+    return ((nodes[ref].word >> sh) & 3u) ? 1u : 0u;
+  };
+  const uint32_t bits = act(n.left) | (act(n.right) << 1);
+  nodes[id].word = (n.word & ~(3u << sh)) | (bits << sh);
+}
+
+hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s)
+{
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(kdRefitKernel, dim3((count + 255) / 256), dim3(256), 0, s, nodes, nodeIds, count, active, which);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------
 // Region activity: the OPTIX_BOUNDS_PROGRAMs (exabrick.cu:250-312, 373-402)
 // ------------------------------------------------------------------------

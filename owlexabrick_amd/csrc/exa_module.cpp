@@ -159,6 +159,16 @@ struct ExaHipRenderer {
   DeviceScene sc{};
   int numFields = 0;
 
+  // region kd-tree (optional; exact front-to-back walk)
+  DevBuf<KdNodeDev> kdNodes;
+  DevBuf<RegionRec> regionRec;
+  DevBuf<int32_t> kdLevelIds;
+  std::vector<int> kdLevelBegin;
+  int32_t kdRoot = EXA_KD_EMPTY;
+  bool haveKd = false;
+  int accel = 1;                     // 1 = kd walk when available, 0 = LBVH
+  float kdLo[3], kdHi[3];
+
   // LBVH
   DevBuf<BvhNode> volNodes, isoNodes;
   DevBuf<int32_t> levelIds;
@@ -233,6 +243,15 @@ struct ExaHipRenderer {
     return 0;
   }
 
+  int kdRefit(const uint8_t *active, int which, hipStream_t s)
+  {
+    for (size_t h = 0; h + 1 < kdLevelBegin.size(); h++)
+      HIP_TRY(this, launchKdRefit(kdNodes.p, kdLevelIds.p + kdLevelBegin[h], kdLevelBegin[h + 1] - kdLevelBegin[h],
+                                  active, which, s));
+    return 0;
+  }
+  bool useKd() const { return haveKd && accel == 1 && !isoEnabled(); }
+
   int refit(DevBuf<BvhNode> &nodes, const uint8_t *active, hipStream_t s)
   {
     for (size_t h = 0; h + 1 < levelBegin.size(); h++) {
@@ -261,6 +280,7 @@ struct ExaHipRenderer {
       if (volDirty) {                       // needVolumeBVHRebuild (OptixRenderer.cpp:533-537)
         HIP_TRY(this, launchVolumeActivity(sc, fs, p, xf.p, volActive.p, s));
         if (refit(volNodes, volActive.p, s)) return 1;
+        if (haveKd && kdRefit(volActive.p, 0, s)) return 1;
         volDirty = false;
       }
       if (needIso && isoDirty) {            // needIsoBVHRebuild (OptixRenderer.cpp:539-543)
@@ -268,6 +288,7 @@ struct ExaHipRenderer {
           HIP_TRY(this, isoNodes.upload(topoTemplate.data(), topoTemplate.size()));
         HIP_TRY(this, launchIsoActivity(sc, fs, isoActive.p, s));
         if (refit(isoNodes, isoActive.p, s)) return 1;
+        if (haveKd && kdRefit(isoActive.p, 1, s)) return 1;
         isoDirty = false;
       }
       HIP_TRY(this, hipEventRecord(ev1, s));
@@ -295,8 +316,14 @@ struct ExaHipRenderer {
     a.stats = statsBuf.p;
     a.errorFlag = errorFlag.p;
     a.debugPixel = debugPixel;
+    a.kdNodes = kdNodes.p;
+    a.regionRec = regionRec.p;
+    a.kdRoot = kdRoot;
+    for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
     HIP_TRY(this, hipEventRecord(ev0, s));
-    HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, isoEnabled(), stats, s));
+    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, stats, s));
+    else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, isoEnabled(), stats, s));
+    last.node_bytes = useKd() ? sizeof(KdNodeDev) : sizeof(BvhNode);
     HIP_TRY(this, hipEventRecord(ev1, s));
     return 0;
   }
@@ -388,6 +415,69 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
     for (size_t i = 0; i < ni; i++) ids[cursor[topo.height[i] - 1]++] = (int32_t)i;
   }
   CREATE_TRY(h->levelIds.upload(ids.data(), ids.size()));
+  // ---- optional region kd-tree: validate, order by height for the refit, upload ----
+  for (int k = 0; k < 3; k++) { h->kdLo[k] = INFINITY; h->kdHi[k] = -INFINITY; }
+  for (uint64_t r = 0; r < scene->numRegions; r++)
+    for (int k = 0; k < 3; k++) {
+      h->kdLo[k] = std::fmin(h->kdLo[k], scene->regions[r].domain_lo[k]);
+      h->kdHi[k] = std::fmax(h->kdHi[k], scene->regions[r].domain_hi[k]);
+    }
+  if (scene->kdNodes != nullptr || (scene->numKdNodes == 0 && scene->numRegions == 1 && scene->kdRoot == ~int32_t(0))) {
+    const uint64_t nk = scene->numKdNodes;
+    auto refOk = [&](int32_t ref) {
+      if (ref == EXA_KD_EMPTY) return true;
+      return ref >= 0 ? uint64_t(ref) < nk : uint64_t(~ref) < scene->numRegions;
+    };
+    bool ok = refOk(scene->kdRoot) && scene->kdRoot != EXA_KD_EMPTY && nk < 0x7fffffffull;
+    for (uint64_t i = 0; ok && i < nk; i++) {
+      const ExaKdNode &n = scene->kdNodes[i];
+      // children must come later in the array (preorder), which also rules out cycles
+      ok = n.axis >= 0 && n.axis <= 2 && refOk(n.left) && refOk(n.right)
+           && (n.left < 0 || uint64_t(n.left) > i) && (n.right < 0 || uint64_t(n.right) > i);
+    }
+    if (!ok) { h->fail("exa_hip_create: malformed kd-tree"); return bail(); }
+    std::vector<int32_t> kh(nk, 1);
+    for (uint64_t ii = nk; ii-- > 0;) {            // children have larger indices: one backward sweep
+      const ExaKdNode &n = scene->kdNodes[ii];
+      int hh = 0;
+      if (n.left >= 0) hh = std::max(hh, kh[n.left]);
+      if (n.right >= 0) hh = std::max(hh, kh[n.right]);
+      kh[ii] = hh + 1;
+    }
+    int kmax = 0;
+    for (uint64_t i = 0; i < nk; i++) kmax = std::max(kmax, kh[i]);
+    std::vector<int> kcount(kmax + 2, 0);
+    for (uint64_t i = 0; i < nk; i++) kcount[kh[i]]++;
+    h->kdLevelBegin.assign(1, 0);
+    for (int hh = 1; hh <= kmax; hh++) h->kdLevelBegin.push_back(h->kdLevelBegin.back() + kcount[hh]);
+    std::vector<int32_t> kids(nk);
+    {
+      std::vector<int> cursor(h->kdLevelBegin.begin(), h->kdLevelBegin.end());
+      for (uint64_t i = 0; i < nk; i++) kids[cursor[kh[i] - 1]++] = (int32_t)i;
+    }
+    std::vector<KdNodeDev> kd(nk);
+    for (uint64_t i = 0; i < nk; i++) {
+      kd[i].split = scene->kdNodes[i].split;
+      kd[i].word = (uint32_t)scene->kdNodes[i].axis;
+      kd[i].left = scene->kdNodes[i].left;
+      kd[i].right = scene->kdNodes[i].right;
+    }
+    std::vector<RegionRec> rec(scene->numRegions);
+    for (uint64_t r = 0; r < scene->numRegions; r++) {
+      const ExaBrickRegion &R = scene->regions[r];
+      RegionRec &q = rec[r];
+      q.lo[0] = R.domain_lo[0]; q.lo[1] = R.domain_lo[1]; q.lo[2] = R.domain_lo[2];
+      q.hi0 = R.domain_hi[0]; q.hi1 = R.domain_hi[1]; q.hi2 = R.domain_hi[2];
+      q.finestLevelCellWidth = R.finestLevelCellWidth;
+      q.firstBrick = scene->leafList[R.leafListBegin];
+      q.listBegin = R.leafListBegin; q.listSize = R.leafListSize; q.pad0 = q.pad1 = 0;
+    }
+    CREATE_TRY(h->kdNodes.upload(kd.data(), kd.size()));
+    CREATE_TRY(h->kdLevelIds.upload(kids.data(), kids.size()));
+    CREATE_TRY(h->regionRec.upload(rec.data(), rec.size()));
+    h->kdRoot = scene->kdRoot;
+    h->haveKd = true;
+  }
   CREATE_TRY(h->volActive.alloc(scene->numRegions));
   CREATE_TRY(h->isoActive.alloc(scene->numRegions));
   CREATE_TRY(h->xf.alloc(size_t(EXA_MAX_CHANNELS) * EXA_NUM_XF_VALUES));
@@ -482,6 +572,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!h || !key) return 1;
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
+  if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
   h->fail(std::string("exa_hip_set_option: unknown key ") + key);
   return 1;
 }

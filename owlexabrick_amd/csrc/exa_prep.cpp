@@ -35,12 +35,22 @@ struct BuildPrim {           // std::pair<box3f,int> of exa/Regions.cpp:75
 struct RegionChunk {
   std::vector<ExaBrickRegion> regions;   // leafListBegin relative to this chunk
   std::vector<int32_t>        leafList;
-  void append(RegionChunk &&o)
+  std::vector<ExaKdNode>      nodes;     // the partition's own kd-tree, refs relative to this chunk
+  // appends o behind this chunk and returns o's root reference translated into this chunk
+  int32_t append(RegionChunk &&o, int32_t oRoot)
   {
     const int32_t base = (int32_t)leafList.size();
+    const int32_t regionBase = (int32_t)regions.size(), nodeBase = (int32_t)nodes.size();
+    auto fix = [&](int32_t ref) {
+      if (ref == EXA_KD_EMPTY) return ref;
+      return ref >= 0 ? ref + nodeBase : ~(~ref + regionBase);
+    };
     regions.reserve(regions.size() + o.regions.size());
     for (ExaBrickRegion r : o.regions) { r.leafListBegin += base; regions.push_back(r); }
     leafList.insert(leafList.end(), o.leafList.begin(), o.leafList.end());
+    nodes.reserve(nodes.size() + o.nodes.size());
+    for (ExaKdNode n : o.nodes) { n.left = fix(n.left); n.right = fix(n.right); nodes.push_back(n); }
+    return fix(oRoot);
   }
 };
 
@@ -49,28 +59,30 @@ struct RegionPartitioner {
   static constexpr size_t kSpawnThreshold = 4096;   // prims; below this recurse inline
 
   // exa/Regions.cpp:32-71 addLeaf
-  static void emitLeaf(const std::vector<BuildPrim> &prims, const float lo[3], const float hi[3],
-                       RegionChunk &out)
+  static int32_t emitLeaf(const std::vector<BuildPrim> &prims, const float lo[3], const float hi[3],
+                          RegionChunk &out)
   {
-    if (lo[0] >= hi[0] || lo[1] >= hi[1] || lo[2] >= hi[2]) return;
+    if (lo[0] >= hi[0] || lo[1] >= hi[1] || lo[2] >= hi[2]) return EXA_KD_EMPTY;
     std::vector<int32_t> ids(prims.size());
     for (size_t i = 0; i < prims.size(); i++) ids[i] = prims[i].brickID;
     std::sort(ids.begin(), ids.end());
     ids.erase(std::unique(ids.begin(), ids.end()), ids.end());   // std::set<int> order
-    if (ids.empty()) return;
+    if (ids.empty()) return EXA_KD_EMPTY;
     ExaBrickRegion r{};
     for (int k = 0; k < 3; k++) { r.domain_lo[k] = lo[k]; r.domain_hi[k] = hi[k]; }
     r.leafListBegin = (int32_t)out.leafList.size();
     r.leafListSize  = (int32_t)ids.size();
     out.leafList.insert(out.leafList.end(), ids.begin(), ids.end());
     out.regions.push_back(r);
+    return ~int32_t(out.regions.size() - 1);
   }
 
-  // exa/Regions.cpp:73-179 buildRec
-  void partition(std::vector<BuildPrim> &prims, const float dlo[3], const float dhi[3], RegionChunk &out)
+  // exa/Regions.cpp:73-179 buildRec.  Returns the kd reference of this subtree inside `out`:
+  // >= 0 node index, < 0 leaf (~region index), EXA_KD_EMPTY nothing.
+  int32_t partition(std::vector<BuildPrim> &prims, const float dlo[3], const float dhi[3], RegionChunk &out)
   {
-    if (prims.empty()) return;
-    for (int i = 0; i < 3; i++) if (dhi[i] == dlo[i]) return;
+    if (prims.empty()) return EXA_KD_EMPTY;
+    for (int i = 0; i < 3; i++) if (dhi[i] == dlo[i]) return EXA_KD_EMPTY;
 
     // candidate plane per axis: the brick-domain face strictly inside the box that is
     // closest to the box centre; first found wins ties (:84-107)
@@ -104,7 +116,7 @@ struct RegionPartitioner {
       splitPos = bestPos[dim];
       break;
     }
-    if (splitDim < 0) { emitLeaf(prims, dlo, dhi, out); return; }  // (:131-134)
+    if (splitDim < 0) return emitLeaf(prims, dlo, dhi, out);        // (:131-134)
 
     float llo[3], lhi[3], rlo[3], rhi[3];
     for (int k = 0; k < 3; k++) { llo[k] = rlo[k] = dlo[k]; lhi[k] = rhi[k] = dhi[k]; }
@@ -128,19 +140,26 @@ struct RegionPartitioner {
     // chunks are concatenated in that same order.
     const bool spawn = left.size() >= kSpawnThreshold && right.size() >= kSpawnThreshold
                        && workersFree.fetch_sub(1) > 0;
+    const int32_t me = (int32_t)out.nodes.size();
+    out.nodes.push_back(ExaKdNode{ splitPos, splitDim, EXA_KD_EMPTY, EXA_KD_EMPTY });
+    int32_t leftRef, rightRef;
     if (spawn) {
       RegionChunk rightOut, leftOut;
-      std::thread t([&] { partition(right, rlo, rhi, rightOut); });
-      partition(left, llo, lhi, leftOut);
+      int32_t rr = EXA_KD_EMPTY, lr = EXA_KD_EMPTY;
+      std::thread t([&] { rr = partition(right, rlo, rhi, rightOut); });
+      lr = partition(left, llo, lhi, leftOut);
       t.join();
       workersFree.fetch_add(1);
-      out.append(std::move(rightOut));
-      out.append(std::move(leftOut));
+      rightRef = out.append(std::move(rightOut), rr);
+      leftRef = out.append(std::move(leftOut), lr);
     } else {
       if (left.size() >= kSpawnThreshold && right.size() >= kSpawnThreshold) workersFree.fetch_add(1);
-      partition(right, rlo, rhi, out);
-      partition(left, llo, lhi, out);
+      rightRef = partition(right, rlo, rhi, out);
+      leftRef = partition(left, llo, lhi, out);
     }
+    out.nodes[me].left = leftRef;      // lower side of the split plane
+    out.nodes[me].right = rightRef;    // upper side
+    return me;
   }
 };
 
@@ -170,6 +189,8 @@ struct ExaPrep {
   std::vector<ExaBrick>       bricks;
   std::vector<ExaBrickRegion> regions;
   std::vector<int32_t>        leafList;
+  std::vector<ExaKdNode>      kdNodes;
+  int32_t                     kdRoot = EXA_KD_EMPTY;
   std::unique_ptr<float[]>    scalars;        // numFields * totalCells, first touched in parallel
   std::vector<uint64_t>       channelOffset;
   uint64_t totalCells = 0;
@@ -304,9 +325,10 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
   RegionPartitioner part;
   part.workersFree = numThreads - 1;
   RegionChunk all;
-  part.partition(prims, blo, bhi, all);
+  P->kdRoot = part.partition(prims, blo, bhi, all);
   P->regions = std::move(all.regions);
   P->leafList = std::move(all.leafList);
+  P->kdNodes = std::move(all.nodes);
 
   lap("partition");
   // finest level + value range per region (exa/Regions.cpp:290-306)
@@ -337,6 +359,9 @@ int exa_prep_scene(const ExaPrep *P, ExaHipScene *out)
   out->channelOffset = P->channelOffset.data();
   out->totalCells = P->totalCells;
   out->numFields = P->numFields;
+  out->kdNodes = P->kdNodes.data();
+  out->numKdNodes = P->kdNodes.size();
+  out->kdRoot = P->kdRoot;
   for (int k = 0; k < 3; k++) { out->voxelBounds_lo[k] = P->boundsLo[k]; out->voxelBounds_hi[k] = P->boundsHi[k]; }
   return 0;
 }

@@ -30,13 +30,14 @@ def band_xf(lo=0.35, hi=0.65):
 class Case:
     def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
                  space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
-                 xfm=None, grad_iso=1, multi=True, xf_domains=None):
+                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None):
         self.scene, self.W, self.H = scene, W, H
         self.grad, self.iso, self.dt = grad, iso, dt
         self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
         self.opacity_scale, self.space_skipping = opacity_scale, space_skipping
         self.ao, self.ao_length, self.clip, self.frameID = ao, ao_length, clip, frameID
         self.camera, self.xfm, self.grad_iso, self.multi = camera, xfm, grad_iso, multi
+        self.accel = accel
         nf = len(scene.fields)
         self.nprim = nf if multi else 1
         self.colormap_channel = 0 if (multi or nf < 2) else 1
@@ -86,6 +87,8 @@ class Case:
         from owlexabrick_amd import binding
         prep = binding.Prep(self.scene, num_region_fields=len(self.scene.fields) if self.multi else 1)
         R = binding.Renderer(prep, device=device, multiFieldDvr=self.multi)
+        if self.accel is not None:
+            R.setOption("accel", self.accel)
         lo, hi = prep.voxel_bounds()
         cam = self.cam(lo, hi)
         if self.xfm is not None:

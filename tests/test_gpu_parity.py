@@ -54,9 +54,11 @@ CASES = {
 }
 
 
+@pytest.mark.parametrize("accel", [1, 0], ids=["kd", "lbvh"])
 @pytest.mark.parametrize("name", sorted(CASES))
-def test_hip_matches_oracle(name):
+def test_hip_matches_oracle(name, accel):
     case = CASES[name]()
+    case.accel = accel
     o = case.run_oracle()
     h = case.run_hip(stats=True)
     r = compare(o, h, name)
@@ -189,7 +191,11 @@ def test_full_frame_properties_at_benchmark_size():
     case = Case(sc, W=2048, H=2048, grad=1, xf_domains=[(0.0, 1.0)])
     R = case.hip_renderer()
     R.setOption("tile_order", 0)
+    R.setOption("accel", 0)
+    lb = R.render()
+    R.setOption("accel", 1)
     a = R.render()
+    assert np.array_equal(a, lb)                              # kd walk and LBVH restart pick the same segments
     R.setOption("tile_order", 1)
     R.resizeFrameBuffer((2048, 2048))
     b = R.render()

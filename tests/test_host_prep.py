@@ -103,3 +103,33 @@ def test_artificial_restatement_matches_reference_tool_output():
         sc = scenes.example(name)
         assert np.array_equal(sc.meta["cells"], cells)
         assert np.array_equal(sc.fields[0], scal)
+
+
+@pytest.mark.parametrize("sc", list(all_scenes()), ids=lambda s: s.name)
+def test_exported_kd_tree_reproduces_region_domains(sc):
+    """the recursion tree of buildRec: walking it from the union box, cutting at every
+    split plane, must land on each region's domain exactly, every region exactly once."""
+    P = binding.Prep(sc, num_threads=3)
+    R, K, root = P.regions(), P.kd_nodes(), P.scene.kdRoot
+    lo = R["dom_lo"].min(axis=0).astype(np.float32)
+    hi = R["dom_hi"].max(axis=0).astype(np.float32)
+    seen = np.zeros(len(R), dtype=np.int32)
+    stack = [(root, lo.copy(), hi.copy())]
+    while stack:
+        ref, l, h = stack.pop()
+        if ref == binding.KD_EMPTY:
+            continue
+        if ref < 0:
+            r = ~ref
+            seen[r] += 1
+            assert np.array_equal(R[r]["dom_lo"], l) and np.array_equal(R[r]["dom_hi"], h)
+            continue
+        n = K[ref]
+        assert l[n["axis"]] < n["split"] < h[n["axis"]]
+        assert (n["left"] < 0 or n["left"] > ref) and (n["right"] < 0 or n["right"] > ref)   # preorder
+        hl, lr = h.copy(), l.copy()
+        hl[n["axis"]] = n["split"]
+        lr[n["axis"]] = n["split"]
+        stack.append((int(n["left"]), l, hl))
+        stack.append((int(n["right"]), lr, h))
+    assert (seen == 1).all()
