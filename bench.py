@@ -35,7 +35,7 @@ def algorithmic_bytes(st, pixels, frame_id=0):
     scalar actually read, per segment the 44 B region record + 64 B per LBVH node
     fetched, per pixel 4 B RGBA8 + 16 B accum write (+16 B accum read after frame 0)."""
     return (36 * (st["brick_visits"]) + 4 * st["corner_loads"]
-            + 44 * (st["segments"] + st["iso_segments"]) + 64 * st["nodes_visited"]
+            + 44 * (st["segments"] + st["iso_segments"]) + st.get("node_bytes", 64) * st["nodes_visited"]
             + pixels * (4 + 16 + (16 if frame_id > 0 else 0)))
 
 
@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--tile-order", type=int, default=int(os.environ.get("EXA_TILE_ORDER", "1")))
+    ap.add_argument("--accel", type=int, default=int(os.environ.get("EXA_ACCEL", "1")),
+                    help="1 = region kd-tree walked front to back (default), 0 = LBVH restarted per segment")
     ap.add_argument("--dump", default=None, help="write the frame as PNG (rank 0)")
     args = ap.parse_args()
 
@@ -113,6 +115,7 @@ def main():
     xf = harness.default_xf()
     R.resizeFrameBuffer((W, H))
     R.setOption("tile_order", args.tile_order)
+    R.setOption("accel", args.accel)
     R.setShard(rank, world)
     R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
     R.updateXF(0, xf[:, 3], xf[:, :3], scene.value_range, 1.0)
@@ -193,7 +196,13 @@ def main():
                        "samples_per_frame": samples_total, "kernel_ms_max_over_ranks": float(kmax.item())},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "renderFrameKernel", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": B},
+                         "kernel": "renderFrameKdKernel" if args.accel else "renderFrameKernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": B,
+                         "bytes_breakdown": {"brick_records_and_leaf_entries": 36 * st["brick_visits"],
+                                             "cell_scalars": 4 * st["corner_loads"],
+                                             "region_records": 44 * st["segments"],
+                                             "accel_nodes": st.get("node_bytes", 64) * st["nodes_visited"],
+                                             "framebuffer": 20 * st["pixels"]}},
         }
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(traffic_file):
