@@ -119,6 +119,8 @@ typedef struct ExaHipStats {
                              16-B kd nodes, see node_bytes                         */
   uint64_t node_bytes;    /* bytes per node of the structure that was walked       */
   uint64_t pixels;        /* pixels rendered by this handle (its tile shard)       */
+  uint64_t diag[9];       /* kd kernel diagnostics: {waves,lanes} x {brick visit, sample epilogue,
+                             kd node step, leaf accept}, then kd-interval/slab-test mismatches */
   float    kernel_ms;     /* hipEvent time of the last render launch               */
   float    rebuild_ms;    /* hipEvent time of the last activity+refit pass         */
 } ExaHipStats;

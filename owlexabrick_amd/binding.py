@@ -62,10 +62,14 @@ class ExaHipScene(C.Structure):
 class ExaHipStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ("segments", "sample_evals", "samples", "brick_visits", "corner_loads",
                                           "iso_segments", "iso_evals", "nodes_visited", "node_bytes", "pixels")] + \
-               [("kernel_ms", C.c_float), ("rebuild_ms", C.c_float)]
+               [("diag", C.c_uint64 * 9), ("kernel_ms", C.c_float), ("rebuild_ms", C.c_float)]
 
     def asdict(self):
-        return {n: (int(getattr(self, n)) if t is C.c_uint64 else float(getattr(self, n))) for n, t in self._fields_}
+        d = {}
+        for n, t in self._fields_:
+            v = getattr(self, n)
+            d[n] = int(v) if t is C.c_uint64 else (float(v) if t is C.c_float else [int(x) for x in v])
+        return d
 
 
 BRICK_DTYPE = np.dtype([("lower", "<i4", 3), ("size", "<i4", 3), ("level", "<i4"), ("begin", "<u4")])

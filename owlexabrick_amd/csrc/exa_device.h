@@ -59,10 +59,14 @@ struct DeviceScene {
   uint32_t numInternal;            // internal LBVH nodes
 };
 
-enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 12 };
+enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 7, kSegQueue = 6 };
 
 enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CORNER_LOADS,
-                ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES, ST_COUNT };
+                ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES,
+                // wave-level diagnostics of the instrumented v2 kernel: executions of a phase by a wave,
+                // and lanes active in them (lane utilisation = lanes / (64 * waves))
+                ST_W_BRICK, ST_L_BRICK, ST_W_FINAL, ST_L_FINAL, ST_W_NODE, ST_L_NODE, ST_W_LEAF, ST_L_LEAF,
+                ST_KD_MISMATCH, ST_COUNT };
 
 struct RenderArgs {
   DeviceScene        sc;

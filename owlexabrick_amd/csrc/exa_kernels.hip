@@ -66,6 +66,15 @@ struct Ctx {
   unsigned long long st[ST_COUNT];
   bool guardTripped;
   __device__ __forceinline__ void count(int slot, unsigned long long n = 1) { if (STATS) st[slot] += n; }
+  // one count per wave execution (first active lane) + one per active lane
+  __device__ __forceinline__ void phase(int waveSlot)
+  {
+    if (STATS) {
+      const unsigned long long m = __ballot(1);
+      if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) st[waveSlot]++;
+      st[waveSlot + 1]++;
+    }
+  }
 };
 
 // ------------------------------------------------------------------------
@@ -691,58 +700,92 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs
   }
 }
 
-// advance to the next leaf whose subtree is active; returns the region id or -1
+// Per-lane queue of accepted segments (region, t0, t1) in LDS.  Which segments a ray
+// gets depends only on the walk (each accepted leaf advances ray.tmin to t1*1.0000001f,
+// exabrick.cu:1698), not on the march, so a lane may walk ahead of its march.  The walk
+// therefore runs in wave-wide refill bursts — every lane with a free queue slot steps its
+// own walk — instead of one or two lanes at a time whenever a lane's segment ends.
+struct SegQueue {
+  int head, count;        // circular: head = next slot to read
+};
+
+// one step of the walk: pop / descend one level / accept-or-skip a leaf
 template <bool STATS>
-__device__ __forceinline__ int kdNextLeaf(Ctx<STATS> &C, KdWalk &w, const RenderArgs &a, float *stackF,
-                                          const V3 org, const V3 dir, const int which, const float tminCur)
+__device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, float &walkTmin, const RenderArgs &a,
+                                       float *stackF, int *qRegion, float *qT, const Ray &ray, const int which)
 {
-  for (;;) {
-    if (w.ref == EXA_KD_DONE) return -1;
-    if (w.ref == EXA_KD_EMPTY || !(w.tf > tminCur)) { kdPop(C, w, a, stackF); continue; }
-    if (w.ref < 0) {                               // leaf: hand it out, then continue with the stack
-      const int region = ~w.ref;
-      w.ref = EXA_KD_EMPTY;
-      return region;
+  if (w.ref == EXA_KD_EMPTY || !(w.tf > walkTmin)) { kdPop(C, w, a, stackF); return; }
+  if (w.ref < 0) {
+    // Leaf.  Its interval [w.tn, w.tf] is max/min over exactly the plane distances the
+    // reference's slab test (exabrick.cu:197-210, 213-238) evaluates for this region's domain,
+    // (plane-o)/d each: the faces are split planes of the path (or faces of the root box) and
+    // the looser planes on the path cannot win a max/min.  No further division is needed; the
+    // instrumented variant re-does the slab test and counts mismatches.
+    const int region = ~w.ref;
+    C.phase(ST_W_LEAF);
+    const float t0 = fmaxf(walkTmin, w.tn);
+    const float t1 = w.tf;
+    const bool hit = t0 < t1;
+    if (STATS) {
+      const float4 *rp = reinterpret_cast<const float4 *>(a.regionRec + region);
+      const float4 r0 = rp[0], r1 = rp[1];
+      Ray rr = ray; rr.tmin = walkTmin;
+      float s0, s1;
+      const bool shit = boxTest(rr, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), s0, s1);
+      if (shit != hit || (hit && (s0 != t0 || s1 != t1))) C.st[ST_KD_MISMATCH]++;
     }
-    const int4 n = *reinterpret_cast<const int4 *>(a.kdNodes + w.ref);
-    C.count(ST_NODES);
-    const float split = __int_as_float(n.x);
-    const int axis = n.y & 3;
-    const int bits = (n.y >> (2 + 2 * which)) & 3;          // bit0 left active, bit1 right active
-    const float o = axis == 0 ? org.x : (axis == 1 ? org.y : org.z);
-    const float d = axis == 0 ? dir.x : (axis == 1 ? dir.y : dir.z);
-    if (d == 0.f) {
-      // parallel to the plane: only the side that strictly contains the origin can be hit
-      // (boxTest turns lo==o / hi==o into a miss, see exabrick.cu:201-208 with NaN-ignoring min/max)
-      if (o < split && (bits & 1)) w.ref = n.z;
-      else if (o > split && (bits & 2)) w.ref = n.w;
-      else kdPop(C, w, a, stackF);
-      continue;
+    if (hit) {
+      int slot = q.head + q.count;
+      slot = slot >= kSegQueue ? slot - kSegQueue : slot;
+      qRegion[slot * 256] = region;
+      qT[(2 * slot) * 256] = t0;
+      qT[(2 * slot + 1) * 256] = t1;
+      q.count++;
+      walkTmin = t1 * (1.0000001f);                          // exabrick.cu:1698
     }
-    const float ts = (split - o) / d;                       // same expression as the slab test
-    const bool nearIsLeft = d > 0.f;
-    const int nearRef = nearIsLeft ? n.z : n.w, farRef = nearIsLeft ? n.w : n.z;
-    const bool nearAct = (bits & (nearIsLeft ? 1 : 2)) != 0, farAct = (bits & (nearIsLeft ? 2 : 1)) != 0;
-    if (ts >= w.tf) {                                        // plane behind the interval: near side only
-      if (nearAct) w.ref = nearRef; else kdPop(C, w, a, stackF);
-    } else if (ts <= w.tn) {                                 // plane before the interval: far side only
-      if (farAct) w.ref = farRef; else kdPop(C, w, a, stackF);
-    } else if (nearAct) {
-      if (farAct) {                                          // push far [ts,tf], go near [tn,ts]
-        C.stack[w.head * 256] = farRef;
-        stackF[(2 * w.head) * 256] = ts;
-        stackF[(2 * w.head + 1) * 256] = w.tf;
-        w.head = w.head == kKdStack - 1 ? 0 : w.head + 1;
-        if (w.count == kKdStack) w.dropped = true; else w.count++;
-      }
-      w.ref = nearRef;
-      w.tf = ts;
-    } else if (farAct) {
-      w.ref = farRef;
-      w.tn = ts;
-    } else {
-      kdPop(C, w, a, stackF);
+    w.ref = EXA_KD_EMPTY;
+    kdPop(C, w, a, stackF);
+    return;
+  }
+  const int4 n = *reinterpret_cast<const int4 *>(a.kdNodes + w.ref);
+  C.count(ST_NODES);
+  C.phase(ST_W_NODE);
+  const float split = __int_as_float(n.x);
+  const int axis = n.y & 3;
+  const int bits = (n.y >> (2 + 2 * which)) & 3;            // bit0 left active, bit1 right active
+  const float o = axis == 0 ? ray.org.x : (axis == 1 ? ray.org.y : ray.org.z);
+  const float d = axis == 0 ? ray.dir.x : (axis == 1 ? ray.dir.y : ray.dir.z);
+  if (d == 0.f) {
+    // parallel to the plane: only the side that strictly contains the origin can be hit
+    // (boxTest turns lo==o / hi==o into a miss, exabrick.cu:201-208 with NaN-ignoring min/max)
+    if (o < split && (bits & 1)) w.ref = n.z;
+    else if (o > split && (bits & 2)) w.ref = n.w;
+    else kdPop(C, w, a, stackF);
+    return;
+  }
+  const float ts = (split - o) / d;                         // same expression as the slab test
+  const bool nearIsLeft = d > 0.f;
+  const int nearRef = nearIsLeft ? n.z : n.w, farRef = nearIsLeft ? n.w : n.z;
+  const bool nearAct = (bits & (nearIsLeft ? 1 : 2)) != 0, farAct = (bits & (nearIsLeft ? 2 : 1)) != 0;
+  if (ts >= w.tf) {                                          // plane behind the interval: near side only
+    if (nearAct) w.ref = nearRef; else kdPop(C, w, a, stackF);
+  } else if (ts <= w.tn) {                                   // plane before the interval: far side only
+    if (farAct) w.ref = farRef; else kdPop(C, w, a, stackF);
+  } else if (nearAct) {
+    if (farAct) {                                            // push far [ts,tf], go near [tn,ts]
+      C.stack[w.head * 256] = farRef;
+      stackF[(2 * w.head) * 256] = ts;
+      stackF[(2 * w.head + 1) * 256] = w.tf;
+      w.head = w.head == kKdStack - 1 ? 0 : w.head + 1;
+      if (w.count == kKdStack) w.dropped = true; else w.count++;
     }
+    w.ref = nearRef;
+    w.tf = ts;
+  } else if (farAct) {
+    w.ref = farRef;
+    w.tn = ts;
+  } else {
+    kdPop(C, w, a, stackF);
   }
 }
 
@@ -753,7 +796,9 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
-  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * 256 * sizeof(int)) + threadIdx.x;
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * 256 * 4) + threadIdx.x;
+  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * 256 * 12) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * 256 * 12 + size_t(kSegQueue) * 256 * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += 256) xfLds[i] = a.xf[i];
   __syncthreads();
 
@@ -813,6 +858,9 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
       w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
     }
 
+    SegQueue q; q.head = 0; q.count = 0;
+    float walkTmin = ray.tmin;
+
     // ---- segment / sample state ----
     bool haveSeg = false;
     int listBegin = 0, listSize = 0, firstBrick = 0, finestLevelCellWidth = 1;
@@ -826,26 +874,30 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
 
     for (unsigned iter = 0;; iter++) {
       if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
-      if (!haveSeg) {
-        // ---- next segment: first leaf in front-to-back order that passes the slab test ----
-        float t0 = 0.f;
-        bool found = false;
+      // ---- refill burst: as soon as one lane of the wave has run dry, every lane with a
+      //      free queue slot advances its own walk (all lanes of the wave take part) ----
+      if (__any(!haveSeg && q.count == 0 && w.ref != EXA_KD_DONE)) {
         for (;;) {
-          const int region = kdNextLeaf(C, w, a, stackF, ray.org, ray.dir, 0, ray.tmin);
-          if (region < 0) break;
-          const float4 *rp = reinterpret_cast<const float4 *>(a.regionRec + region);
-          const float4 r0 = rp[0], r1 = rp[1];
-          if (boxTest(ray, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), t0, t1)) {   // exabrick.cu:213-238
-            const int4 r2 = *reinterpret_cast<const int4 *>(rp + 2);
-            listBegin = r2.x; listSize = r2.y;
-            firstBrick = __float_as_int(r1.w);
-            finestLevelCellWidth = (int)r1.z;
-            dt = a.p.dt * r1.z;                                                    // :1129
-            found = true;
-            break;
-          }
+          const bool want = q.count < kSegQueue && w.ref != EXA_KD_DONE;
+          if (!__any(want)) break;
+          if (want) kdStep(C, w, q, walkTmin, a, stackF, qRegion, qT, ray, 0);
         }
-        if (!found) break;
+      }
+      if (!haveSeg) {
+        // ---- next segment from this lane's queue ----
+        if (q.count == 0) break;                                                   // walk finished: ray done
+        const int region = qRegion[q.head * 256];
+        const float t0 = qT[(2 * q.head) * 256];
+        t1 = qT[(2 * q.head + 1) * 256];
+        q.head = q.head == kSegQueue - 1 ? 0 : q.head + 1;
+        q.count--;
+        {
+          const RegionInfo ri = a.sc.regionInfo[region];
+          listBegin = ri.listBegin; listSize = ri.listSize;
+          firstBrick = ri.firstBrick;
+          finestLevelCellWidth = (int)ri.finestLevelCellWidth;
+          dt = a.p.dt * ri.finestLevelCellWidth;                                   // :1129
+        }
         C.count(ST_SEGMENTS);
         haveSeg = true;
         t_i = firstSampleT(t0, dt, interleavedSamplingOffset);                     // :1141-1144
@@ -863,6 +915,7 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
       }
 
       // ---- one brick visit ----
+      C.phase(ST_W_BRICK);
       if (brickID != loadedBrick) {
         hb0 = a.sc.bricks[2 * brickID]; hb1 = a.sc.bricks[2 * brickID + 1];
         loadedBrick = brickID;
@@ -872,6 +925,7 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
       if (child < listSize) { brickID = a.sc.leafList[listBegin + child]; continue; }
 
       // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
+      C.phase(ST_W_FINAL);
       if (B.sumW > 1e-20f) {
         C.count(ST_SAMPLES);
         const float cellValue = B.sumWV / B.sumW;
@@ -897,8 +951,7 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
         pixelColor.w = 1.f;
         break;
       }
-      if (t_next >= t1) {                                                          // segment done
-        ray.tmin = t1 * (1.0000001f);                                              // :1698
+      if (t_next >= t1) {                                                          // segment done (:1698 is in kdStep)
         haveSeg = false;
         continue;
       }
@@ -943,7 +996,7 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
 hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
-  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack) * 256 * 12;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * 256 * 12;
   const dim3 grid(numBlocks), block(256);
   if (stats) {
     if (grad) hipLaunchKernelGGL((renderFrameKdKernel<true, true>), grid, block, lds, s, a);

@@ -609,6 +609,7 @@ static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, h
     h->last.segments = c[ST_SEGMENTS]; h->last.sample_evals = c[ST_SAMPLE_EVALS]; h->last.samples = c[ST_SAMPLES];
     h->last.brick_visits = c[ST_BRICK_VISITS]; h->last.corner_loads = c[ST_CORNER_LOADS];
     h->last.iso_segments = c[ST_ISO_SEGMENTS]; h->last.iso_evals = c[ST_ISO_EVALS]; h->last.nodes_visited = c[ST_NODES];
+    for (int i = 0; i < 9; i++) h->last.diag[i] = c[ST_W_BRICK + i];
   }
   h->last.pixels = px;
   return 0;

@@ -1,0 +1,21 @@
+"""phase/lane diagnostics of the v2 kernel on the bench scene (GPU box)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from common import Case
+from owlexabrick_amd import scenes, binding, harness
+import numpy as np
+scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
+sc = scenes.config("c4_exajet", scale=scale)
+case = Case(sc, W=2048, H=2048, grad=1, xf_domains=[(0.0, 1.0)])
+R = case.hip_renderer()
+_, st = R.renderStats()
+d = st["diag"]
+names = ["brick", "final", "node", "leaf"]
+print({k: v for k, v in st.items() if k != "diag"})
+for i, n in enumerate(names):
+    w, l = d[2 * i], d[2 * i + 1]
+    print(f"{n:6s} wave-execs {w:.4g} lanes {l:.4g} util {l / max(1, 64 * w):.3f}")
+print("kd mismatches", d[8])
+for k in range(3):
+    R.render()
+print("kernel_ms", R.stats()["kernel_ms"])

@@ -64,6 +64,7 @@ def test_hip_matches_oracle(name, accel):
     r = compare(o, h, name)
     assert r["accum_bad"] == 0 and r["rgba_bad"] == 0, r
     assert {k: o[2][k] for k in STAT_KEYS} == {k: h[2][k] for k in STAT_KEYS}   # identical work, sample for sample
+    assert h[2]["diag"][8] == 0        # kd interval == the reference's slab test, every leaf
 
 
 def test_ao_rays_match_up_to_trig_ulps():

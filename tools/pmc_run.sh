@@ -5,6 +5,7 @@
 set -u
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+case "$OUT" in /*) ;; *) OUT="$PWD/$OUT";; esac
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 PASSES=(
