@@ -213,7 +213,10 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
 
 /* tuning knobs that never change results: "tile_order" 0 = row-major tile launch
  * order, 1 = XCD-aware supertile order; "accel" 0 = LBVH with restart per segment,
- * 1 = region kd-tree walked front to back (default when the scene carries one) */
+ * 1 = region kd-tree walked front to back (default when the scene carries one).
+ * One knob moves results within the stated float tolerance: "fast_math" 1 (default)
+ * evaluates the opacity correction powf as exp2(dt*log2(x)) on the hardware
+ * transcendental units (~2 ulp), 0 uses the library powf (<1 ulp). */
 int exa_hip_set_option(ExaHipRenderer *, const char *key, int32_t value);
 
 const char *exa_hip_last_error(const ExaHipRenderer * /* may be NULL: creation errors */);

@@ -88,6 +88,7 @@ struct RenderArgs {
   unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
   int32_t           *errorFlag;     // set when a loop guard trips
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
+  int32_t            ablate;        // timing experiments only (wrong pixels): 1 skip integrateVolume, 2 skip basis
 };
 
 // ---- launchers implemented in exa_kernels.hip ----
@@ -98,7 +99,7 @@ hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, 
 // refit one height class of internal nodes: box of each child = union below it
 hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
                        const uint8_t *active, hipStream_t s);
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool stats, hipStream_t s);
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool stats, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
 hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,

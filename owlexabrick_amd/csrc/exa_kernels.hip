@@ -255,6 +255,78 @@ __device__ __forceinline__ void addBasisFunctions(Ctx<STATS> &C, Basis &B, const
 #undef EXA_CORNER
 }
 
+// Same sums as addBasisFunctions with fewer instructions: validity is a product of
+// per-axis predicates, so the per-axis weights are masked to 0 once (6 selects) instead of
+// selecting every accumulator at every corner.  A skipped corner then adds +-0, which
+// leaves a sum unchanged (the sums start at +0 and can never become -0), so the
+// accumulators see bit-identical values.  The speculative read of an out-of-brick corner
+// is clamped onto a cell that an in-brick corner of the same sample reads as well.
+template <bool DERIV, bool STATS>
+__device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4 b0, const int4 b1,
+                                             const float *__restrict__ field, V3 pos)
+{
+  const int sx = b0.w, sy = b1.x, sz = b1.y;
+  const float invCw = __int_as_float((127 - b1.z) << 23);   // exact 2^-level
+  const float lpx = (pos.x - float(b0.x)) * invCw - 0.5f;
+  const float lpy = (pos.y - float(b0.y)) * invCw - 0.5f;
+  const float lpz = (pos.z - float(b0.z)) * invCw - 0.5f;
+  const int lx = max(-1, int(floorf(lpx))), ly = max(-1, int(floorf(lpy))), lz = max(-1, int(floorf(lpz)));
+  const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
+  const float fx = lpx - float(lx), fy = lpy - float(ly), fz = lpz - float(lz);
+  const bool vlx = lx >= 0 && lx < sx, vhx = hx < sx;
+  const bool vly = ly >= 0 && ly < sy, vhy = hy < sy;
+  const bool vlz = lz >= 0 && lz < sz, vhz = hz < sz;
+  const int cxl = min(max(lx, 0), sx - 1), cxh = min(hx, sx - 1);
+  const int cyl = min(max(ly, 0), sy - 1), cyh = min(hy, sy - 1);
+  const int czl = min(max(lz, 0), sz - 1), czh = min(hz, sz - 1);
+  const uint32_t sxy = (uint32_t)(sx * sy);
+  const uint32_t zl = (uint32_t)b1.w + (uint32_t)czl * sxy, zh = (uint32_t)b1.w + (uint32_t)czh * sxy;
+  const uint32_t yl = (uint32_t)(cyl * sx), yh = (uint32_t)(cyh * sx);
+  const uint32_t rowLL = zl + yl, rowHL = zl + yh, rowLH = zh + yl, rowHH = zh + yh;
+  const float s000 = field[rowLL + cxl], s100 = field[rowLL + cxh];
+  const float s010 = field[rowHL + cxl], s110 = field[rowHL + cxh];
+  const float s001 = field[rowLH + cxl], s101 = field[rowLH + cxh];
+  const float s011 = field[rowHH + cxl], s111 = field[rowHH + cxh];
+  C.count(ST_BRICK_VISITS);
+  if (STATS) C.st[ST_CORNER_LOADS] += (unsigned)((int(vlx) + int(vhx)) * (int(vly) + int(vhy)) * (int(vlz) + int(vhz)));
+  // masked per-axis weights: (1-frac) for the low cell, frac for the high cell
+  const float wxl = vlx ? 1.f - fx : 0.f, wxh = vhx ? fx : 0.f;
+  const float wyl = vly ? 1.f - fy : 0.f, wyh = vhy ? fy : 0.f;
+  const float wzl = vlz ? 1.f - fz : 0.f, wzh = vhz ? fz : 0.f;
+  // (z*y) first, then *x: the reference's association (exabrick.cu:647 etc.)
+  const float zyLL = wzl * wyl, zyLH = wzl * wyh, zyHL = wzh * wyl, zyHH = wzh * wyh;
+  if (DERIV) {
+    // d/dx weight = +-(z*y), d/dy = +-(z*x), d/dz = +-(y*x), zero for an out-of-brick corner
+    const float mxl = vlx ? -1.f : 0.f, mxh = vhx ? 1.f : 0.f;
+    const float myl = vly ? -1.f : 0.f, myh = vhy ? 1.f : 0.f;
+    const float mzl = vlz ? -1.f : 0.f, mzh = vhz ? 1.f : 0.f;
+    const float zxLL = wzl * wxl, zxLH = wzl * wxh, zxHL = wzh * wxl, zxHH = wzh * wxh;   // [z][x]
+    const float yxLL = wyl * wxl, yxLH = wyl * wxh, yxHL = wyh * wxl, yxHH = wyh * wxh;   // [y][x]
+#define EXA_ACC(S, ZY, WX, MX, ZX, MY, YX, MZ)                                               \
+    {                                                                                        \
+      const float dx_ = (ZY) * (MX), dy_ = (ZX) * (MY), dz_ = (YX) * (MZ);                   \
+      B.sumDC.x += dx_; B.sumDC.y += dy_; B.sumDC.z += dz_;                                  \
+      B.sumD.x += dx_ * (S); B.sumD.y += dy_ * (S); B.sumD.z += dz_ * (S);                   \
+      const float w_ = (ZY) * (WX);                                                          \
+      B.sumW += w_; B.sumWV += w_ * (S);                                                     \
+    }
+    EXA_ACC(s000, zyLL, wxl, mxl, zxLL, myl, yxLL, mzl)
+    EXA_ACC(s100, zyLL, wxh, mxh, zxLH, myl, yxLH, mzl)
+    EXA_ACC(s010, zyLH, wxl, mxl, zxLL, myh, yxHL, mzl)
+    EXA_ACC(s110, zyLH, wxh, mxh, zxLH, myh, yxHH, mzl)
+    EXA_ACC(s001, zyHL, wxl, mxl, zxHL, myl, yxLL, mzh)
+    EXA_ACC(s101, zyHL, wxh, mxh, zxHH, myl, yxLH, mzh)
+    EXA_ACC(s011, zyHH, wxl, mxl, zxHL, myh, yxHL, mzh)
+    EXA_ACC(s111, zyHH, wxh, mxh, zxHH, myh, yxHH, mzh)
+#undef EXA_ACC
+  } else {
+#define EXA_ACC(S, ZY, WX) { const float w_ = (ZY) * (WX); B.sumW += w_; B.sumWV += w_ * (S); }
+    EXA_ACC(s000, zyLL, wxl) EXA_ACC(s100, zyLL, wxh) EXA_ACC(s010, zyLH, wxl) EXA_ACC(s110, zyLH, wxh)
+    EXA_ACC(s001, zyHL, wxl) EXA_ACC(s101, zyHL, wxh) EXA_ACC(s011, zyHH, wxl) EXA_ACC(s111, zyHH, wxh)
+#undef EXA_ACC
+  }
+}
+
 // exabrick.cu:781-806 samplePoint / :883-928 samplePointWithDerivative
 template <bool DERIV, bool STATS>
 __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &derivatives,
@@ -281,7 +353,7 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
 }
 
 // exabrick.cu:988-1016 integrateVolume
-template <bool STATS>
+template <bool FAST, bool STATS>
 __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
                                                 float cellValue, V3 gradient, int finestLevelCellWidth, int channel)
 {
@@ -292,7 +364,11 @@ __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, C
     const float scale = fabsf(dot(lightDir, gradient)) / sqrtf(dot(gradient, gradient) * dot(lightDir, lightDir));
     sample.x *= scale; sample.y *= scale; sample.z *= scale;
   }
-  sample.w = 1.f - powf(1.f - sample.w, actual_dt);
+  // opacity correction 1-(1-a)^dt (exabrick.cu:1011).  FAST: pow as exp2(dt*log2(x)) on the
+  // hardware transcendental units — for x in [0,1] and dt of a few voxels within ~2 ulp of a
+  // correctly rounded powf (CUDA's own powf is specified to 4 ulp), x==0 -> 0, x==1 -> 1.
+  if (FAST) sample.w = 1.f - __builtin_amdgcn_exp2f(actual_dt * __builtin_amdgcn_logf(1.f - sample.w));
+  else      sample.w = 1.f - powf(1.f - sample.w, actual_dt);
   const float k = (1.f - pixelColor.w) * sample.w;
   pixelColor.x += k * sample.x;
   pixelColor.y += k * sample.y;
@@ -335,7 +411,7 @@ __device__ __forceinline__ void integrateBrick(Ctx<STATS> &C, Color4 &pixelColor
       C.count(ST_SAMPLE_EVALS);
       if (samplePoint<GRAD, STATS>(C, cellValue, grad, ri, pos, c)) {
         C.count(ST_SAMPLES);
-        integrateVolume(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, c);
+        integrateVolume<false>(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, c);
       }
     }
     if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) break;
@@ -789,8 +865,8 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, fl
   }
 }
 
-template <bool GRAD, bool STATS>
-__global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
+template <bool GRAD, bool FAST, bool STATS>
+__global__ __launch_bounds__(256, 4) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -920,7 +996,8 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
         hb0 = a.sc.bricks[2 * brickID]; hb1 = a.sc.bricks[2 * brickID + 1];
         loadedBrick = brickID;
       }
-      addBasisFunctions<GRAD, STATS>(C, B, hb0, hb1, field, pos);
+      if (!(a.ablate & 2)) addBasisFast<GRAD, STATS>(C, B, hb0, hb1, field, pos);
+      else { B.sumW += 1.f; B.sumWV += pos.x * 1e-4f; }
       child++;
       if (child < listSize) { brickID = a.sc.leafList[listBegin + child]; continue; }
 
@@ -933,7 +1010,8 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
                             B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
-        integrateVolume(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, chan);
+        if (!(a.ablate & 1)) integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, chan);
+        else pixelColor.x += cellValue * 1e-9f + grad.x * 1e-12f;
       }
       chan++;
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
@@ -993,18 +1071,20 @@ __global__ __launch_bounds__(256) void renderFrameKdKernel(const RenderArgs a)
   }
 }
 
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool stats, hipStream_t s)
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * 256 * 12;
   const dim3 grid(numBlocks), block(256);
+#define EXA_LAUNCH(G, F, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, S>), grid, block, lds, s, a)
   if (stats) {
-    if (grad) hipLaunchKernelGGL((renderFrameKdKernel<true, true>), grid, block, lds, s, a);
-    else      hipLaunchKernelGGL((renderFrameKdKernel<false, true>), grid, block, lds, s, a);
+    if (grad) { if (fast) EXA_LAUNCH(true, true, true); else EXA_LAUNCH(true, false, true); }
+    else      { if (fast) EXA_LAUNCH(false, true, true); else EXA_LAUNCH(false, false, true); }
   } else {
-    if (grad) hipLaunchKernelGGL((renderFrameKdKernel<true, false>), grid, block, lds, s, a);
-    else      hipLaunchKernelGGL((renderFrameKdKernel<false, false>), grid, block, lds, s, a);
+    if (grad) { if (fast) EXA_LAUNCH(true, true, false); else EXA_LAUNCH(true, false, false); }
+    else      { if (fast) EXA_LAUNCH(false, true, false); else EXA_LAUNCH(false, false, false); }
   }
+#undef EXA_LAUNCH
   return hipGetLastError();
 }
 

@@ -190,6 +190,8 @@ struct ExaHipRenderer {
   int rank = 0, world = 1;
   int tileOrder = 0;
   int debugPixel = -1;
+  int ablate = 0;
+  int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
   DevBuf<float4> accum;
   DevBuf<uint32_t> color;
   DevBuf<int32_t> tileMap;
@@ -316,12 +318,13 @@ struct ExaHipRenderer {
     a.stats = statsBuf.p;
     a.errorFlag = errorFlag.p;
     a.debugPixel = debugPixel;
+    a.ablate = ablate;
     a.kdNodes = kdNodes.p;
     a.regionRec = regionRec.p;
     a.kdRoot = kdRoot;
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
     HIP_TRY(this, hipEventRecord(ev0, s));
-    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, stats, s));
+    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, stats, s));
     else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, isoEnabled(), stats, s));
     last.node_bytes = useKd() ? sizeof(KdNodeDev) : sizeof(BvhNode);
     HIP_TRY(this, hipEventRecord(ev1, s));
@@ -573,6 +576,8 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
+  if (!std::strcmp(key, "ablate")) { h->ablate = value; return 0; }
+  if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
   h->fail(std::string("exa_hip_set_option: unknown key ") + key);
   return 1;
 }

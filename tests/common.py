@@ -30,7 +30,7 @@ def band_xf(lo=0.35, hi=0.65):
 class Case:
     def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
                  space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
-                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None):
+                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None):
         self.scene, self.W, self.H = scene, W, H
         self.grad, self.iso, self.dt = grad, iso, dt
         self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
@@ -38,6 +38,7 @@ class Case:
         self.ao, self.ao_length, self.clip, self.frameID = ao, ao_length, clip, frameID
         self.camera, self.xfm, self.grad_iso, self.multi = camera, xfm, grad_iso, multi
         self.accel = accel
+        self.fast_math = fast_math
         nf = len(scene.fields)
         self.nprim = nf if multi else 1
         self.colormap_channel = 0 if (multi or nf < 2) else 1
@@ -89,6 +90,8 @@ class Case:
         R = binding.Renderer(prep, device=device, multiFieldDvr=self.multi)
         if self.accel is not None:
             R.setOption("accel", self.accel)
+        if self.fast_math is not None:
+            R.setOption("fast_math", self.fast_math)
         lo, hi = prep.voxel_bounds()
         cam = self.cam(lo, hi)
         if self.xfm is not None:
@@ -133,6 +136,12 @@ class Case:
 ACCUM_ATOL = 2e-5
 ACCUM_RTOL = 1e-4
 RGBA_MAX_LSB = 1
+# A ray stops when its opacity reaches 0.98 (exabrick.cu:49,1180).  An ulp of difference in a
+# transcendental can move that decision by one sample for a rare pixel; the pixel then moves by
+# at most the remaining transmittance (0.02) times its colour.  Allowed for at most FLIP_FRACTION
+# of the pixels; every other pixel must meet ACCUM_ATOL/RTOL.
+FLIP_BOUND = 0.021
+FLIP_FRACTION = 5e-4
 
 
 def compare(oracle_out, hip_out, what=""):
@@ -143,6 +152,8 @@ def compare(oracle_out, hip_out, what=""):
     o8 = harness.unpack_rgba8(o_rgba).astype(np.int32)
     h8 = harness.unpack_rgba8(h_rgba).astype(np.int32)
     d8 = np.abs(o8 - h8)
-    return dict(what=what, accum_max=float(da.max()), accum_bad=int((da > tol).sum()),
+    nflip = int(((da > tol).any(axis=-1)).sum())
+    flips_ok = nflip <= max(1, int(FLIP_FRACTION * da.shape[0] * da.shape[1])) and float(da.max()) <= FLIP_BOUND
+    return dict(what=what, accum_max=float(da.max()), accum_bad=int((da > tol).sum()), flip_pixels=nflip, flips_ok=flips_ok,
                 rgba_max=int(d8.max()), rgba_bad=int((d8 > RGBA_MAX_LSB).sum()),
                 rgba_diff_px=int((d8.max(axis=-1) > 0).sum()), exact=bool(np.array_equal(o_acc, h_acc)))

@@ -59,12 +59,24 @@ CASES = {
 def test_hip_matches_oracle(name, accel):
     case = CASES[name]()
     case.accel = accel
+    case.fast_math = 0          # library powf: the work counters must then match sample for sample
     o = case.run_oracle()
     h = case.run_hip(stats=True)
     r = compare(o, h, name)
     assert r["accum_bad"] == 0 and r["rgba_bad"] == 0, r
     assert {k: o[2][k] for k in STAT_KEYS} == {k: h[2][k] for k in STAT_KEYS}   # identical work, sample for sample
     assert h[2]["diag"][8] == 0        # kd interval == the reference's slab test, every leaf
+
+
+@pytest.mark.parametrize("name", ["ex3_grad", "c1_64", "amr_grad", "amr_band", "amr_2ch", "amr_inside", "gen_exajet"])
+def test_fast_math_default_within_stated_tolerance(name):
+    """the shipped default (hardware exp2/log2 opacity correction) against the oracle"""
+    case = CASES[name]()
+    o, h = case.run_oracle(), case.run_hip(stats=True)
+    r = compare(o, h, name)
+    assert r["flips_ok"] and r["rgba_bad"] <= 3 * r["flip_pixels"], r
+    for k in ("samples", "brick_visits", "segments"):
+        assert abs(o[2][k] - h[2][k]) <= 1e-3 * o[2][k] + 2, (k, o[2][k], h[2][k])
 
 
 def test_ao_rays_match_up_to_trig_ulps():
@@ -81,6 +93,7 @@ def test_ao_rays_match_up_to_trig_ulps():
 def test_hip_matches_golden_fixture(name):
     g = np.load(os.path.join(ROOT, "tests", "golden", f"oracle_{name}.npz"))
     case, frames = make_case(name)
+    case.fast_math = 0
     rgba, acc, st = case.run_hip(frames=frames, stats=True)
     assert np.abs(acc - g["accum"]).max() <= ACCUM_ATOL
     d = np.abs(rgba.view(np.uint8).astype(int) - g["rgba"].view(np.uint8).astype(int))
@@ -108,7 +121,7 @@ def test_region_activity_matches_bounds_programs():
 
 def test_state_changes_between_frames():
     # one renderer, a sequence of setter calls as the viewer would issue them
-    case = Case(_amr(), W=64, H=64, grad=1)
+    case = Case(_amr(), W=64, H=64, grad=1, fast_math=0)
     R = case.hip_renderer()
     img0 = R.render()
     R.updateXF(0, band_xf()[:, 3], band_xf()[:, :3], case.xf_domains[0], 1.0)
@@ -131,7 +144,7 @@ def test_state_changes_between_frames():
 
 
 def test_progressive_accumulation_16_frames():
-    case = Case(scenes.example("ex4"), W=64, H=48, grad=1)
+    case = Case(scenes.example("ex4"), W=64, H=48, grad=1, fast_math=0)
     o = case.run_oracle(frames=16)
     h = case.run_hip(frames=16)
     r = compare(o, h)
@@ -211,5 +224,6 @@ def test_full_frame_properties_at_benchmark_size():
     x0 = 1024 - 48
     o = case.run_oracle(window=(x0, x0, x0 + 96, x0 + 96))
     d = np.abs(o[1][x0:x0 + 96, x0:x0 + 96] - acc_skip[x0:x0 + 96, x0:x0 + 96])
-    assert d.max() <= ACCUM_ATOL + 1e-4 * np.abs(o[1]).max()
+    bad = (d > ACCUM_ATOL + 1e-4 * np.abs(o[1]).max()).any(axis=-1).sum()
+    assert bad <= 5 and d.max() <= 0.021          # only termination flips, see tests/common.py
     assert o[2]["samples"] > 0
