@@ -1,0 +1,145 @@
+// exaRender — headless stand-in for the reference's exaViewer (exa/viewer.cpp): same config
+// file, same camera / transfer-function / iso flags, same per-frame call sequence into the
+// renderer, N frames instead of a GLUT loop, result written as binary PPM.
+//   exaRender cfg.exa [--size W H] [--camera px py pz  ix iy iz  ux uy uz] [--fov deg]
+//             [--dt f] [--xf file.xf] [--xf-scale s] [--range lo hi] [--isovals a b] [--isochans a b]
+//             [--clip-box lx ly lz ux uy uz] [--ao] [--ao-length l] [--no-pg] [--no-space-skipping]
+//             [--gradientShadingDVR 0|1] [--gradientShadingISO 0|1] [--frames N] [-o out.ppm] [--info]
+#include "exa_host.h"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+using namespace exa;
+
+namespace {
+// glutViewer/Camera.cpp:94-120 + glutViewer/OWLViewer.cpp:69-109 + exa/viewer.cpp:226-238
+void setupCamera(Renderer &r, vec3f origin, vec3f interest, vec3f up, float fovy, vec2i size)
+{
+  vec3f vz = (interest == origin) ? vec3f(0, 0, 1) : -normalize(interest - origin);
+  vec3f vx = cross(up, vz);
+  vx = dot(vx, vx) < 1e-8f ? vec3f(0, 1, 0) : normalize(vx);
+  vec3f vy = normalize(cross(vz, vx));
+  const float focal = length(interest - origin);
+  if (std::fabs(dot(vz, up)) >= 1e-6f) { vx = normalize(cross(up, vz)); vy = normalize(cross(vz, vx)); }
+  auto eps = [](vec3f v) { return std::fmax(std::fmax(std::fabs(v.x), std::fabs(v.y)), std::fabs(v.z)) * float(1. / (1 << 21)); };
+  const float fd = std::fmax(std::fmax(eps(origin), eps(vx)), focal);
+  const float screen_height = 2.f * tanf(fovy / 2.f * (float)M_PI / 180.f) * fd;
+  const vec3f vertical = screen_height * vy;
+  const vec3f horizontal = (screen_height * (size.x / float(size.y))) * vx;
+  const vec3f lower_left = (-fd) * vz - 0.5f * vertical - 0.5f * horizontal;
+  r.updateCamera(origin, lower_left, horizontal / float(size.x), vertical / float(size.y));
+}
+} // namespace
+
+int main(int argc, char **argv)
+{
+  try {
+    std::string cfgName, outName;
+    vec2i size(600, 400);                                         // viewer default window
+    vec3f vp, vi, vu;                                             // --camera
+    float fov = 70.f, dt = 0.5f, xfScale = 1.f, aoLength = 1e20f;
+    float isoVals[2] = { 0, 0 }; int isoChans[2] = { 0, 0 }, isoOn[2] = { 0, 0 };
+    bool haveRange = false, ao = false, pg = true, skipping = true, gradDVR = true, gradISO = true, info = false, clip = false;
+    float range[2] = { 0, 1 }; box3f clipBox;
+    std::string xfFile;
+    int frames = 1;
+    for (int i = 1; i < argc; i++) {
+      const std::string a = argv[i];
+      auto f = [&]() { if (i + 1 >= argc) throw std::runtime_error("missing value after " + a); return (float)atof(argv[++i]); };
+      if (a == "--size" || a == "-win") { size.x = (int)f(); size.y = (int)f(); }
+      else if (a == "--camera") { vp = { f(), f(), f() }; vi = { f(), f(), f() }; vu = { f(), f(), f() }; }
+      else if (a == "--fov") fov = f();
+      else if (a == "--dt") dt = f();
+      else if (a == "--xf") { if (i + 1 >= argc) throw std::runtime_error("missing file after --xf"); xfFile = argv[++i]; }
+      else if (a == "--xf-scale") xfScale = f();
+      else if (a == "--range") { range[0] = f(); range[1] = f(); haveRange = true; }
+      else if (a == "--isovals") { isoVals[0] = f(); isoVals[1] = f(); isoOn[0] = isoOn[1] = 1; }
+      else if (a == "--isochans") { isoChans[0] = (int)f(); isoChans[1] = (int)f(); }
+      else if (a == "--clip-box") { clipBox.lower = { f(), f(), f() }; clipBox.upper = { f(), f(), f() }; clip = true; }
+      else if (a == "--ao") ao = true;
+      else if (a == "--ao-length") aoLength = f();
+      else if (a == "--no-pg") pg = false;
+      else if (a == "--no-space-skipping") skipping = false;
+      else if (a == "--gradientShadingDVR") gradDVR = f() != 0.f;
+      else if (a == "--gradientShadingISO") gradISO = f() != 0.f;
+      else if (a == "--frames") frames = (int)f();
+      else if (a == "-o") { if (i + 1 >= argc) throw std::runtime_error("missing file after -o"); outName = argv[++i]; }
+      else if (a == "--info") info = true;
+      else if (a[0] != '-') cfgName = a;
+      else throw std::runtime_error("unknown flag " + a);
+    }
+    if (cfgName.empty()) throw std::runtime_error("usage: exaRender cfg.exa [flags]");
+    Config::SP config = Config::parseConfigFile(cfgName);
+    if (!config->bricks.sp) throw std::runtime_error("no bricks file specified");
+    const box3f bounds = config->getBounds();
+    std::printf("bricks %zu cells %zu fields %zu\n", config->bricks.sp->numBricks(), config->bricks.sp->totalNumCells,
+                config->scalarFields.size());
+    for (auto &sf : config->scalarFields)
+      std::printf("field %s range %.9g %.9g elements %zu\n", sf->name.c_str(), sf->valueRange.lower, sf->valueRange.upper, sf->value.size());
+    std::printf("bounds %.9g %.9g %.9g  %.9g %.9g %.9g\n", bounds.lower.x, bounds.lower.y, bounds.lower.z,
+                bounds.upper.x, bounds.upper.y, bounds.upper.z);
+    if (info) return 0;
+
+    std::vector<uint32_t> fb(size_t(size.x) * size.y);
+    Renderer renderer(config->bricks.sp, config->surfaces, config->scalarFields);          // viewer.cpp:1256-1260
+    renderer.setVoxelSpaceTransform(config->bricks.voxelSpaceTransform);
+    renderer.resizeFrameBuffer(fb.data(), size);
+    if (vu != vec3f(0.f)) setupCamera(renderer, vp, vi, vu, fov, size);
+    else setupCamera(renderer, bounds.center() + vec3f(-.3f, .7f, 1.f) * bounds.span(), bounds.center(), vec3f(0, 1, 0), 70.f, size);
+
+    // default transfer function: alpha ramp, grey ramp colour (the PNG colormaps are UI assets)
+    std::vector<float> alpha(NUM_XF_VALUES);
+    std::vector<vec3f> color(NUM_XF_VALUES);
+    for (int i = 0; i < NUM_XF_VALUES; i++) { alpha[i] = i / float(NUM_XF_VALUES - 1); color[i] = vec3f(alpha[i]); }
+    if (!xfFile.empty()) {                                          // 128 raw floats (viewer.cpp:139-145,1147-1152)
+      FILE *f = std::fopen(xfFile.c_str(), "rb");
+      if (!f || std::fread(alpha.data(), sizeof(float), NUM_XF_VALUES, f) != (size_t)NUM_XF_VALUES) throw std::runtime_error("cannot read " + xfFile);
+      std::fclose(f);
+    }
+    for (size_t c = 0; c < config->scalarFields.size(); c++) {      // viewer.cpp:567-575
+      interval<float> dom = config->scalarFields[c]->valueRange;
+      if (haveRange) dom = interval<float>(range[0], range[1]);
+      renderer.updateXF((int)c, alpha.data(), color, dom, xfScale);
+    }
+    renderer.updateIsoValues(isoVals, isoChans, isoOn);
+    renderer.setSpaceSkipping(skipping);
+    renderer.setGradientShadingDVR(gradDVR);
+    renderer.setGradientShadingISO(gradISO);
+    renderer.frameState.ao.enabled = ao;                            // viewer.cpp:944-959
+    renderer.frameState.ao.length = aoLength;
+    renderer.frameState.clipBox.enabled = clip;
+    if (clip) {
+      const box3f wb = renderer.worldSpaceBounds;
+      renderer.frameState.clipBox.coords.lower = wb.lower + clipBox.lower * wb.span();
+      renderer.frameState.clipBox.coords.upper = wb.lower + clipBox.upper * wb.span();
+    }
+    int accumID = 0;
+    double kernelMs = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int fr = 0; fr < frames; fr++) {                            // viewer.cpp:279-288
+      renderer.updateDt(dt);
+      renderer.updateFrameID(accumID);
+      if (pg) ++accumID;
+      renderer.render();
+      kernelMs += renderer.stats().kernel_ms;
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("Avg. after %d frames: %.3f FPS (%.3f ms), kernel %.3f ms\n", frames, frames / sec, 1000.0 * sec / frames, kernelMs / frames);
+    if (!outName.empty()) {
+      FILE *f = std::fopen(outName.c_str(), "wb");
+      if (!f) throw std::runtime_error("cannot write " + outName);
+      std::fprintf(f, "P6\n%d %d\n255\n", size.x, size.y);
+      for (int y = size.y - 1; y >= 0; y--)
+        for (int x = 0; x < size.x; x++) { const uint32_t p = fb[size_t(y) * size.x + x]; const unsigned char rgb[3] = { (unsigned char)(p & 255), (unsigned char)((p >> 8) & 255), (unsigned char)((p >> 16) & 255) }; std::fwrite(rgb, 1, 3, f); }
+      std::fclose(f);
+    }
+    return 0;
+  } catch (const std::exception &e) {
+    std::cerr << "Fatal error " << e.what() << std::endl;
+    return 1;
+  }
+}

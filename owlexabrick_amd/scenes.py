@@ -302,3 +302,30 @@ def config(name, scale=1.0, threads=0, fill=True):
     root = tuple(max(1, int(round(r * scale))) for r in c.pop("root"))
     kind = c.pop("kind")
     return generated(kind=kind, root=root, threads=threads, fill=fill, name=name, **c)
+
+
+def write_exa(scene, directory, name="scene", remap=None):
+    """write the scene in the reference's on-disk formats: `.bricks` (per brick int32
+    size[3], lower[3], level, cellIDs[]; builder/builder.cpp:895-902), one raw-float32
+    `.scalars` per field in cell-id order (exa/ScalarField.cpp:22-34) and the `.exa`
+    config (exa/Config.cpp:88-173).  Returns the config path."""
+    import os
+    os.makedirs(directory, exist_ok=True)
+    with open(os.path.join(directory, name + ".bricks"), "wb") as f:
+        at = 0
+        for rec in np.asarray(scene.bricks7, dtype=np.int32):
+            n = int(rec[0]) * int(rec[1]) * int(rec[2])
+            f.write(rec.tobytes())
+            f.write(np.asarray(scene.cellIDs[at:at + n], dtype=np.int32).tobytes())
+            at += n
+    lines = ["# written by owlexabrick_amd.scenes.write_exa", f"bricks {name}.bricks"]
+    for i, fld in enumerate(scene.fields):
+        np.asarray(fld, dtype=np.float32).tofile(os.path.join(directory, f"{name}_{i}.scalars"))
+        lines.append(f"scalar field{i} {name}_{i}.scalars")
+    if remap is not None:
+        lines.append("remap_from " + " ".join(str(float(v)) for v in remap[0]))
+        lines.append("remap_to " + " ".join(str(float(v)) for v in remap[1]))
+    path = os.path.join(directory, name + ".exa")
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return path

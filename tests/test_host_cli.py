@@ -1,0 +1,76 @@
+"""The C++ host layer (owlexabrick_amd/host): loaders for the reference's file formats and
+the exa::Renderer facade, driven through the headless exaRender CLI."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from common import Case, ROOT, compare
+from owlexabrick_amd import harness, scenes
+
+EXE = os.path.join(ROOT, "owlexabrick_amd", "host", "exaRender")
+
+
+def _run(args):
+    return subprocess.run([EXE] + args, capture_output=True, text=True, timeout=300)
+
+
+def test_config_loaders_and_scalarfield_size_quirk():
+    sc = scenes.example("ex3")
+    with tempfile.TemporaryDirectory() as d:
+        cfg = scenes.write_exa(sc, d, "ex3")
+        r = _run([cfg, "--info"])
+        assert r.returncode == 0, r.stderr
+        out = r.stdout
+        assert "bricks 4 cells 200 fields 1" in out
+        # ScalarField::load sizes by bytes (4x elements) and folds the zero tail into the range
+        assert "elements 800" in out
+        lo, hi = [float(x) for x in out.split("range")[1].split()[:2]]
+        assert lo == 0.0 and hi == 1.0
+        assert "bounds 0 0 0  8 8 4" in out
+
+
+def test_config_expression_vector_and_errors():
+    sc = scenes.example("ex3")
+    with tempfile.TemporaryDirectory() as d:
+        cfg = scenes.write_exa(sc, d, "ex3")
+        with open(cfg, "a") as f:
+            f.write('scalar twice expr "%0 2 *"\nvalue_range 0 3\nvector mag ex3_0.scalars ex3_0.scalars ex3_0.scalars # comment\n')
+        r = _run([cfg, "--info"])
+        assert r.returncode == 0, r.stderr
+        assert "fields 3" in r.stdout and "field twice range 0 3" in r.stdout
+        assert "field mag range 0 1.73205" in r.stdout
+        with open(cfg, "a") as f:
+            f.write("bogus_token 1\n")
+        r = _run([cfg, "--info"])
+        assert r.returncode == 1 and "unknown token 'bogus_token'" in r.stderr
+        r = _run([os.path.join(d, "missing.exa"), "--info"])
+        assert r.returncode == 1 and "error in opening config file" in r.stderr
+
+
+@pytest.mark.gpu
+def test_exarender_matches_binding_and_oracle():
+    sc = scenes.amr(seed=3, root=(2, 2, 2), B=4, levels=3)
+    grey = np.repeat((np.arange(128, dtype=np.float32) / 127.0)[:, None], 4, axis=1)
+    W, H = 80, 48
+    with tempfile.TemporaryDirectory() as d:
+        cfg = scenes.write_exa(sc, d, "amr")
+        out = os.path.join(d, "o.ppm")
+        r = _run([cfg, "--size", str(W), str(H), "-o", out, "--frames", "1", "--isovals", "0.4", "0.4"])
+        assert r.returncode == 0, r.stderr
+        assert "Avg. after 1 frames" in r.stdout
+        data = open(out, "rb").read()
+        hdr = f"P6\n{W} {H}\n255\n".encode()
+        assert data.startswith(hdr)
+        img = np.frombuffer(data[len(hdr):], dtype=np.uint8).reshape(H, W, 3)[::-1]
+    dom = (float(min(sc.fields[0].min(), 0.0)), float(max(sc.fields[0].max(), 0.0)))
+    case = Case(sc, W=W, H=H, grad=1, xf=grey, xf_domains=[dom], iso=[(0.4, 0), (0.4, 0)])
+    case.ao = 1                                     # FrameState default ao.enabled = true ... the CLI turns it off
+    case.ao = 0
+    h = case.run_hip()
+    assert np.array_equal(harness.unpack_rgba8(h[0])[..., :3], img)      # facade == Python binding, same module
+    o = case.run_oracle()
+    r = compare(o, h)
+    assert r["flips_ok"], r
