@@ -31,7 +31,10 @@ void setupCamera(Renderer &r, vec3f origin, vec3f interest, vec3f up, float fovy
   const vec3f vertical = screen_height * vy;
   const vec3f horizontal = (screen_height * (size.x / float(size.y))) * vx;
   const vec3f lower_left = (-fd) * vz - 0.5f * vertical - 0.5f * horizontal;
-  r.updateCamera(origin, lower_left, horizontal / float(size.x), vertical / float(size.y));
+  const vec3f du = horizontal / float(size.x), dv = vertical / float(size.y);
+  std::printf("camera %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g  %.9g %.9g %.9g\n", origin.x, origin.y, origin.z,
+              lower_left.x, lower_left.y, lower_left.z, du.x, du.y, du.z, dv.x, dv.y, dv.z);
+  r.updateCamera(origin, lower_left, du, dv);
 }
 } // namespace
 

@@ -49,6 +49,8 @@ class Case:
         self.xf_domains = xf_domains
 
     def cam(self, lo, hi):
+        if isinstance(self.camera, dict):       # explicit pos/dir00/dirDu/dirDv
+            return self.camera
         if self.camera is not None:
             return harness.camera(self.camera[0], self.camera[1], self.camera[2], self.camera[3], self.W, self.H)
         if self.xfm is not None:

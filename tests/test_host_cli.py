@@ -61,14 +61,14 @@ def test_exarender_matches_binding_and_oracle():
         r = _run([cfg, "--size", str(W), str(H), "-o", out, "--frames", "1", "--isovals", "0.4", "0.4"])
         assert r.returncode == 0, r.stderr
         assert "Avg. after 1 frames" in r.stdout
+        cv = [np.float32(x) for x in r.stdout.split("camera")[1].split()[:12]]
+        cam = dict(pos=np.array(cv[0:3]), dir00=np.array(cv[3:6]), dirDu=np.array(cv[6:9]), dirDv=np.array(cv[9:12]))
         data = open(out, "rb").read()
         hdr = f"P6\n{W} {H}\n255\n".encode()
         assert data.startswith(hdr)
         img = np.frombuffer(data[len(hdr):], dtype=np.uint8).reshape(H, W, 3)[::-1]
     dom = (float(min(sc.fields[0].min(), 0.0)), float(max(sc.fields[0].max(), 0.0)))
-    case = Case(sc, W=W, H=H, grad=1, xf=grey, xf_domains=[dom], iso=[(0.4, 0), (0.4, 0)])
-    case.ao = 1                                     # FrameState default ao.enabled = true ... the CLI turns it off
-    case.ao = 0
+    case = Case(sc, W=W, H=H, grad=1, xf=grey, xf_domains=[dom], iso=[(0.4, 0), (0.4, 0)], camera=cam)
     h = case.run_hip()
     assert np.array_equal(harness.unpack_rgba8(h[0])[..., :3], img)      # facade == Python binding, same module
     o = case.run_oracle()
