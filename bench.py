@@ -70,11 +70,20 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the render path has no CPU fallback")
+    # rehearsal on a one-GPU box: EXA_BENCH_BACKEND=gloo EXA_BENCH_ONE_DEVICE=1 puts every rank on
+    # device 0 and gathers through host memory; the measured configuration is nccl (= RCCL), one GPU per rank
+    backend = os.environ.get("EXA_BENCH_BACKEND", "nccl")
+    if os.environ.get("EXA_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where collectives operate
 
     W = H = args.size
     host_threads = max(1, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
@@ -140,9 +149,17 @@ def main():
             R.render(device_ptr=shard.data_ptr(), stream=stream)       # synchronous, like owlLaunch2D
             return
         R.render(device_ptr=shard.data_ptr(), stream=stream)
-        dist.gather(shard, gathered, dst=0)
+        if backend == "nccl":
+            dist.gather(shard, gathered, dst=0)
+            if rank == 0:
+                torch.cat(gathered, out=gathered_flat)
+        else:
+            host = shard.cpu()
+            hl = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+            dist.gather(host, hl, dst=0)
+            if rank == 0:
+                gathered_flat.copy_(torch.cat(hl))
         if rank == 0:
-            torch.cat(gathered, out=gathered_flat)
             R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=stream)
 
     # work counters of this frame (instrumented kernel variant, same frameID)
@@ -163,15 +180,15 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
     # aggregate per-rank work counters and kernel time
     agg = torch.tensor([st["samples"], st["brick_visits"], st["corner_loads"], st["segments"], st["nodes_visited"],
-                        st["pixels"]], dtype=torch.float64, device=dev)
-    kmax = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=dev)
+                        st["pixels"]], dtype=torch.float64, device=cdev)
+    kmax = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
@@ -224,12 +241,14 @@ def main():
             harness.fill_frame_state(fs, cam, [scene.value_range], xfOpacityScale=1.0, frameID=0)
             P = po.Params(0.5, 1, 0, 0 if args.no_grad else 1, 1, 1, 1)
             cores = os.cpu_count() or 1
-            # calibrate on a 32x32 centre window, then size the crop for ~cpu-seconds
+            # calibrate on a 64x64 centre window (after a warm-up that spins the threads up),
+            # then size the crop for ~cpu-seconds of work
             c0 = W // 2
+            S.render(fs, P, W, H, window=(c0 - 8, c0 - 8, c0 + 8, c0 + 8), nthreads=cores)
             t = time.perf_counter()
-            _, _, st_c = S.render(fs, P, W, H, window=(c0 - 16, c0 - 16, c0 + 16, c0 + 16), nthreads=cores)
+            _, _, st_c = S.render(fs, P, W, H, window=(c0 - 32, c0 - 32, c0 + 32, c0 + 32), nthreads=cores)
             t_cal = max(time.perf_counter() - t, 1e-4)
-            side = int(min(W, max(64, 32 * (args.cpu_seconds / t_cal) ** 0.5))) // 16 * 16
+            side = int(min(W, max(64, 64 * (args.cpu_seconds / t_cal) ** 0.5))) // 16 * 16
             x0 = (W - side) // 2
             t = time.perf_counter()
             rgba_c, acc_c, st_c = S.render(fs, P, W, H, window=(x0, x0, x0 + side, x0 + side), nthreads=cores)

@@ -1041,13 +1041,17 @@ typedef struct {
 
 static void *worker(void *arg)
 {
+  /* work items are 8x8 pixel blocks handed out from a shared counter */
   Job *J = (Job *)arg;
+  const int bw = (J->x1 - J->x0 + 7) / 8, bh = (J->y1 - J->y0 + 7) / 8;
   for (;;) {
     pthread_mutex_lock(J->mu);
-    int y = (*J->nextRow)++;
+    int b = (*J->nextRow)++;
     pthread_mutex_unlock(J->mu);
-    if (y >= J->y1) break;
-    for (int x = J->x0; x < J->x1; x++) render_pixel(&J->C, x, y, J->W, J->H, J->rgba, J->accum4);
+    if (b >= bw * bh) break;
+    const int bx0 = J->x0 + (b % bw) * 8, by0 = J->y0 + (b / bw) * 8;
+    for (int y = by0; y < by0 + 8 && y < J->y1; y++)
+      for (int x = bx0; x < bx0 + 8 && x < J->x1; x++) render_pixel(&J->C, x, y, J->W, J->H, J->rgba, J->accum4);
   }
   return NULL;
 }
@@ -1062,7 +1066,7 @@ void or_render(const OrScene *S, const OrFrameState *fs, const OrParams *P,
   or_volume_active(S, fs, P, volActive);
   or_iso_active(S, fs, isoActive);
   pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
-  volatile int nextRow = y0;
+  volatile int nextRow = 0;
   Job *jobs = (Job *)xmalloc((size_t)nthreads * sizeof(Job));
   pthread_t *th = (pthread_t *)xmalloc((size_t)nthreads * sizeof(pthread_t));
   for (int i = 0; i < nthreads; i++) {
