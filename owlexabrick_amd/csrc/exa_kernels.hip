@@ -829,8 +829,12 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, fl
   const float split = __int_as_float(n.x);
   const int axis = n.y & 3;
   const int bits = (n.y >> (2 + 2 * which)) & 3;            // bit0 left active, bit1 right active
-  const float o = axis == 0 ? ray.org.x : (axis == 1 ? ray.org.y : ray.org.z);
-  const float d = axis == 0 ? ray.dir.x : (axis == 1 ? ray.dir.y : ray.dir.z);
+  // select on VALUES (copies first): selecting between struct members by address makes the
+  // compiler index a scratch copy of the ray
+  const float ox = ray.org.x, oy = ray.org.y, oz = ray.org.z, dx = ray.dir.x, dy = ray.dir.y, dz = ray.dir.z;
+  float o = axis == 0 ? ox : oy, d = axis == 0 ? dx : dy;
+  o = axis == 2 ? oz : o;
+  d = axis == 2 ? dz : d;
   if (d == 0.f) {
     // parallel to the plane: only the side that strictly contains the origin can be hit
     // (boxTest turns lo==o / hi==o into a miss, exabrick.cu:201-208 with NaN-ignoring min/max)
@@ -865,8 +869,8 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, fl
   }
 }
 
-template <bool GRAD, bool FAST, bool STATS>
-__global__ __launch_bounds__(256, 4) void renderFrameKdKernel(const RenderArgs a)
+template <bool GRAD, bool FAST, bool MULTI, bool STATS>
+__global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -942,11 +946,12 @@ __global__ __launch_bounds__(256, 4) void renderFrameKdKernel(const RenderArgs a
     int listBegin = 0, listSize = 0, firstBrick = 0, finestLevelCellWidth = 1;
     float dt = 0.f, t1 = 0.f, t_i = 0.f, t_last = 0.f, t_next = 0.f, actual_dt = 0.f;
     V3 pos = mk(0.f, 0.f, 0.f);
-    int child = 0, chan = 0, brickID = 0, loadedBrick = -1;
+    int child = 0, chan = 0, brickID = 0, loadedBrick = -1;      // chan stays 0 (and folds away) unless MULTI
     int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 0, 0);
     Basis B;
     B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
-    const float *field = a.sc.scalars + a.sc.channelOffset[0];
+    const float *field0 = a.sc.scalars + a.sc.channelOffset[0];   // wave-uniform
+    const float *field = field0;
 
     for (unsigned iter = 0;; iter++) {
       if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
@@ -984,8 +989,8 @@ __global__ __launch_bounds__(256, 4) void renderFrameKdKernel(const RenderArgs a
         actual_dt = t_next - t_last;
         t_last = t_next;
         pos = ray.org + t_sample * ray.dir;
-        child = 0; chan = 0; brickID = firstBrick;
-        field = a.sc.scalars + a.sc.channelOffset[0];
+        child = 0; brickID = firstBrick;
+        if (MULTI) { chan = 0; field = field0; }
         B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
         C.count(ST_SAMPLE_EVALS);
       }
@@ -996,7 +1001,7 @@ __global__ __launch_bounds__(256, 4) void renderFrameKdKernel(const RenderArgs a
         hb0 = a.sc.bricks[2 * brickID]; hb1 = a.sc.bricks[2 * brickID + 1];
         loadedBrick = brickID;
       }
-      if (!(a.ablate & 2)) addBasisFast<GRAD, STATS>(C, B, hb0, hb1, field, pos);
+      if (!(a.ablate & 2)) addBasisFast<GRAD, STATS>(C, B, hb0, hb1, MULTI ? field : field0, pos);
       else { B.sumW += 1.f; B.sumWV += pos.x * 1e-4f; }
       child++;
       if (child < listSize) { brickID = a.sc.leafList[listBegin + child]; continue; }
@@ -1010,16 +1015,18 @@ __global__ __launch_bounds__(256, 4) void renderFrameKdKernel(const RenderArgs a
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
                             B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
-        if (!(a.ablate & 1)) integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, chan);
+        if (!(a.ablate & 1)) integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, MULTI ? chan : 0);
         else pixelColor.x += cellValue * 1e-9f + grad.x * 1e-12f;
       }
-      chan++;
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0; brickID = firstBrick;
-      if (chan < numChannels) {
-        field = a.sc.scalars + a.sc.channelOffset[chan];
-        C.count(ST_SAMPLE_EVALS);
-        continue;
+      if (MULTI) {
+        chan++;
+        if (chan < numChannels) {
+          field = a.sc.scalars + a.sc.channelOffset[chan];
+          C.count(ST_SAMPLE_EVALS);
+          continue;
+        }
       }
       // ---- end of this step (:1180-1183) ----
       if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) {
@@ -1041,8 +1048,7 @@ __global__ __launch_bounds__(256, 4) void renderFrameKdKernel(const RenderArgs a
         t_last = t_next;
         pos = ray.org + t_sample * ray.dir;
       }
-      chan = 0;
-      field = a.sc.scalars + a.sc.channelOffset[0];
+      if (MULTI) { chan = 0; field = field0; }
       C.count(ST_SAMPLE_EVALS);
     }
 
@@ -1076,14 +1082,17 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
   if (numBlocks <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * 256 * 12;
   const dim3 grid(numBlocks), block(256);
-#define EXA_LAUNCH(G, F, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, S>), grid, block, lds, s, a)
-  if (stats) {
-    if (grad) { if (fast) EXA_LAUNCH(true, true, true); else EXA_LAUNCH(true, false, true); }
-    else      { if (fast) EXA_LAUNCH(false, true, true); else EXA_LAUNCH(false, false, true); }
+  const bool multi = a.p.numPrimaryChannels > 1;
+#define EXA_LAUNCH(G, F, M, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, S>), grid, block, lds, s, a)
+#define EXA_PICK(G, F, M) do { if (stats) EXA_LAUNCH(G, F, M, true); else EXA_LAUNCH(G, F, M, false); } while (0)
+  if (grad) {
+    if (fast) { if (multi) EXA_PICK(true, true, true); else EXA_PICK(true, true, false); }
+    else      { if (multi) EXA_PICK(true, false, true); else EXA_PICK(true, false, false); }
   } else {
-    if (grad) { if (fast) EXA_LAUNCH(true, true, false); else EXA_LAUNCH(true, false, false); }
-    else      { if (fast) EXA_LAUNCH(false, true, false); else EXA_LAUNCH(false, false, false); }
+    if (fast) { if (multi) EXA_PICK(false, true, true); else EXA_PICK(false, true, false); }
+    else      { if (multi) EXA_PICK(false, false, true); else EXA_PICK(false, false, false); }
   }
+#undef EXA_PICK
 #undef EXA_LAUNCH
   return hipGetLastError();
 }
