@@ -59,7 +59,7 @@ struct DeviceScene {
   uint32_t numInternal;            // internal LBVH nodes
 };
 
-enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 5, kSegQueue = 5 };
+enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 4, kSegQueue = 4 };
 
 enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CORNER_LOADS,
                 ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES,

@@ -748,29 +748,40 @@ hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso,
 // pace of its slowest lane in every loop level, flattened it only idles in the
 // short per-sample epilogue.  Per-sample arithmetic and its order are unchanged.
 // ========================================================================
+// small counters of the walk and the segment queue share one register:
+//   bits 0-3 stack head | 4-7 stack count | 8 dropped | 12-15 queue head | 16-19 queue count
+struct Packed {
+  unsigned v;
+  __device__ __forceinline__ int get(int sh) const { return (v >> sh) & 15; }
+  __device__ __forceinline__ void set(int sh, int x) { v = (v & ~(15u << sh)) | ((unsigned)x << sh); }
+};
+enum { PK_SHEAD = 0, PK_SCOUNT = 4, PK_DROPPED = 8, PK_QHEAD = 12, PK_QCOUNT = 16 };
+
 struct KdWalk {
   int   ref;            // current subtree reference, or KD_DONE
   float tn, tf;         // its interval along the ray
-  int   head, count;    // short stack (circular, in LDS)
-  bool  dropped;        // an entry fell off the bottom: restart from the root when empty
   float tEnd;           // end of the root interval
+  Packed pk;            // short stack head/count/dropped (circular stack in LDS) + queue head/count
 };
 #define EXA_KD_DONE (EXA_KD_EMPTY + 1)
 
 template <bool STATS>
 __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs &a, float *stackF)
 {
-  if (w.count > 0) {
-    w.head = w.head == 0 ? kKdStack - 1 : w.head - 1;
-    w.count--;
-    w.ref = C.stack[w.head * 256];
-    w.tn = stackF[(2 * w.head) * 256];
-    w.tf = stackF[(2 * w.head + 1) * 256];
-  } else if (w.dropped && w.tf < w.tEnd) {
+  const int count = w.pk.get(PK_SCOUNT);
+  if (count > 0) {
+    int head = w.pk.get(PK_SHEAD);
+    head = head == 0 ? kKdStack - 1 : head - 1;
+    w.pk.set(PK_SHEAD, head);
+    w.pk.set(PK_SCOUNT, count - 1);
+    w.ref = C.stack[head * 256];
+    w.tn = stackF[(2 * head) * 256];
+    w.tf = stackF[(2 * head + 1) * 256];
+  } else if (w.pk.get(PK_DROPPED) && w.tf < w.tEnd) {
     w.ref = a.kdRoot;                  // short-stack restart: everything before tf is done
     w.tn = w.tf;
     w.tf = w.tEnd;
-    w.dropped = false;
+    w.pk.set(PK_DROPPED, 0);
   } else {
     w.ref = EXA_KD_DONE;
   }
@@ -781,13 +792,10 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs
 // exabrick.cu:1698), not on the march, so a lane may walk ahead of its march.  The walk
 // therefore runs in wave-wide refill bursts — every lane with a free queue slot steps its
 // own walk — instead of one or two lanes at a time whenever a lane's segment ends.
-struct SegQueue {
-  int head, count;        // circular: head = next slot to read
-};
 
 // one step of the walk: pop / descend one level / accept-or-skip a leaf
 template <bool STATS>
-__device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, float &walkTmin, const RenderArgs &a,
+__device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a,
                                        float *stackF, int *qRegion, float *qT, const Ray &ray, const int which)
 {
   if (w.ref == EXA_KD_EMPTY || !(w.tf > walkTmin)) { kdPop(C, w, a, stackF); return; }
@@ -811,12 +819,13 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, fl
       if (shit != hit || (hit && (s0 != t0 || s1 != t1))) C.st[ST_KD_MISMATCH]++;
     }
     if (hit) {
-      int slot = q.head + q.count;
+      const int qc = w.pk.get(PK_QCOUNT);
+      int slot = w.pk.get(PK_QHEAD) + qc;
       slot = slot >= kSegQueue ? slot - kSegQueue : slot;
       qRegion[slot * 256] = region;
       qT[(2 * slot) * 256] = t0;
       qT[(2 * slot + 1) * 256] = t1;
-      q.count++;
+      w.pk.set(PK_QCOUNT, qc + 1);
       walkTmin = t1 * (1.0000001f);                          // exabrick.cu:1698
     }
     w.ref = EXA_KD_EMPTY;
@@ -853,11 +862,12 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, fl
     if (farAct) w.ref = farRef; else kdPop(C, w, a, stackF);
   } else if (nearAct) {
     if (farAct) {                                            // push far [ts,tf], go near [tn,ts]
-      C.stack[w.head * 256] = farRef;
-      stackF[(2 * w.head) * 256] = ts;
-      stackF[(2 * w.head + 1) * 256] = w.tf;
-      w.head = w.head == kKdStack - 1 ? 0 : w.head + 1;
-      if (w.count == kKdStack) w.dropped = true; else w.count++;
+      const int head = w.pk.get(PK_SHEAD), count = w.pk.get(PK_SCOUNT);
+      C.stack[head * 256] = farRef;
+      stackF[(2 * head) * 256] = ts;
+      stackF[(2 * head + 1) * 256] = w.tf;
+      w.pk.set(PK_SHEAD, head == kKdStack - 1 ? 0 : head + 1);
+      if (count == kKdStack) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count + 1);
     }
     w.ref = nearRef;
     w.tf = ts;
@@ -870,7 +880,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, SegQueue &q, fl
 }
 
 template <bool GRAD, bool FAST, bool MULTI, bool STATS>
-__global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a)
+__global__ __launch_bounds__(256, 6) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -927,7 +937,7 @@ __global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a
 
     // ---- walk set-up: interval of the kd root along the ray ----
     KdWalk w;
-    w.head = 0; w.count = 0; w.dropped = false;
+    w.pk.v = 0;
     {
       Ray whole = ray; whole.tmin = -INFINITY; whole.tmax = INFINITY;
       float r0, r1;
@@ -938,14 +948,13 @@ __global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a
       w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
     }
 
-    SegQueue q; q.head = 0; q.count = 0;
     float walkTmin = ray.tmin;
 
     // ---- segment / sample state ----
     bool haveSeg = false;
-    int listBegin = 0, listSize = 0, firstBrick = 0, finestLevelCellWidth = 1;
-    float dt = 0.f, t1 = 0.f, t_i = 0.f, t_last = 0.f, t_next = 0.f, actual_dt = 0.f;
-    V3 pos = mk(0.f, 0.f, 0.f);
+    int listBegin = 0, listSize = 0, firstBrick = 0;
+    float flcw = 1.f;                     // region.finestLevelCellWidth; dt = launch.dt * flcw (:1129)
+    float t1 = 0.f, t_i = 0.f, t_last = 0.f, t_sample = 0.f, actual_dt = 0.f;
     int child = 0, chan = 0, brickID = 0, loadedBrick = -1;      // chan stays 0 (and folds away) unless MULTI
     int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 0, 0);
     Basis B;
@@ -957,38 +966,39 @@ __global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a
       if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
       // ---- refill burst: as soon as one lane of the wave has run dry, every lane with a
       //      free queue slot advances its own walk (all lanes of the wave take part) ----
-      if (__any(!haveSeg && q.count == 0 && w.ref != EXA_KD_DONE)) {
+      if (__any(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
         for (;;) {
-          const bool want = q.count < kSegQueue && w.ref != EXA_KD_DONE;
+          const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
           if (!__any(want)) break;
-          if (want) kdStep(C, w, q, walkTmin, a, stackF, qRegion, qT, ray, 0);
+          if (want) kdStep(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0);
         }
       }
       if (!haveSeg) {
         // ---- next segment from this lane's queue ----
-        if (q.count == 0) break;                                                   // walk finished: ray done
-        const int region = qRegion[q.head * 256];
-        const float t0 = qT[(2 * q.head) * 256];
-        t1 = qT[(2 * q.head + 1) * 256];
-        q.head = q.head == kSegQueue - 1 ? 0 : q.head + 1;
-        q.count--;
+        const int qc = w.pk.get(PK_QCOUNT);
+        if (qc == 0) break;                                                        // walk finished: ray done
+        const int qh = w.pk.get(PK_QHEAD);
+        const int region = qRegion[qh * 256];
+        const float t0 = qT[(2 * qh) * 256];
+        t1 = qT[(2 * qh + 1) * 256];
+        w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
+        w.pk.set(PK_QCOUNT, qc - 1);
         {
           const RegionInfo ri = a.sc.regionInfo[region];
           listBegin = ri.listBegin; listSize = ri.listSize;
           firstBrick = ri.firstBrick;
-          finestLevelCellWidth = (int)ri.finestLevelCellWidth;
-          dt = a.p.dt * ri.finestLevelCellWidth;                                   // :1129
+          flcw = ri.finestLevelCellWidth;
         }
         C.count(ST_SEGMENTS);
         haveSeg = true;
-        t_i = firstSampleT(t0, dt, interleavedSamplingOffset);                     // :1141-1144
-        t_last = t0;
+        t_i = firstSampleT(t0, a.p.dt * flcw, interleavedSamplingOffset);          // :1141-1144
         // first step of the segment (:1158-1166)
-        t_next = fminf(t_i, t1);
-        const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
-        actual_dt = t_next - t_last;
-        t_last = t_next;
-        pos = ray.org + t_sample * ray.dir;
+        {
+          const float t_next = fminf(t_i, t1);
+          t_sample = 0.5f * (fminf(t1, t_next) + t0);
+          actual_dt = t_next - t0;
+          t_last = t_next;
+        }
         child = 0; brickID = firstBrick;
         if (MULTI) { chan = 0; field = field0; }
         B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
@@ -1001,8 +1011,7 @@ __global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a
         hb0 = a.sc.bricks[2 * brickID]; hb1 = a.sc.bricks[2 * brickID + 1];
         loadedBrick = brickID;
       }
-      if (!(a.ablate & 2)) addBasisFast<GRAD, STATS>(C, B, hb0, hb1, MULTI ? field : field0, pos);
-      else { B.sumW += 1.f; B.sumWV += pos.x * 1e-4f; }
+      addBasisFast<GRAD, STATS>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
       child++;
       if (child < listSize) { brickID = a.sc.leafList[listBegin + child]; continue; }
 
@@ -1015,8 +1024,7 @@ __global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
                             B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
-        if (!(a.ablate & 1)) integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, finestLevelCellWidth, MULTI ? chan : 0);
-        else pixelColor.x += cellValue * 1e-9f + grad.x * 1e-12f;
+        integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, (int)flcw, MULTI ? chan : 0);
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0; brickID = firstBrick;
@@ -1036,17 +1044,16 @@ __global__ __launch_bounds__(256, 5) void renderFrameKdKernel(const RenderArgs a
         pixelColor.w = 1.f;
         break;
       }
-      if (t_next >= t1) {                                                          // segment done (:1698 is in kdStep)
+      if (t_last >= t1) {                        // t_last holds this step's t_next: segment done (:1182; :1698 is in kdStep)
         haveSeg = false;
         continue;
       }
-      t_i += dt;
-      t_next = fminf(t_i, t1);
+      t_i += a.p.dt * flcw;
       {
-        const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
+        const float t_next = fminf(t_i, t1);
+        t_sample = 0.5f * (fminf(t1, t_next) + t_last);
         actual_dt = t_next - t_last;
         t_last = t_next;
-        pos = ray.org + t_sample * ray.dir;
       }
       if (MULTI) { chan = 0; field = field0; }
       C.count(ST_SAMPLE_EVALS);
