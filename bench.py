@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--tile-order", type=int, default=int(os.environ.get("EXA_TILE_ORDER", "0")))
     ap.add_argument("--accel", type=int, default=int(os.environ.get("EXA_ACCEL", "1")),
                     help="1 = region kd-tree walked front to back (default), 0 = LBVH restarted per segment")
+    ap.add_argument("--iso", type=float, default=None, help="enable one implicit iso-surface at this value (channel 0)")
     ap.add_argument("--dump", default=None, help="write the frame as PNG (rank 0)")
     args = ap.parse_args()
 
@@ -128,7 +129,12 @@ def main():
     R.setShard(rank, world)
     R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
     R.updateXF(0, xf[:, 3], xf[:, :3], scene.value_range, 1.0)
-    R.updateIsoValues([0, 0], [0, 0], [0, 0])
+    for c in range(1, len(scene.fields)):
+        R.updateXF(c, xf[:, 3], xf[:, :3], (0.0, 1.0), 1.0)
+    if args.iso is not None:
+        R.updateIsoValues([args.iso, 0], [0, 0], [1, 0])
+    else:
+        R.updateIsoValues([0, 0], [0, 0], [0, 0])
     R.setSpaceSkipping(True)
     R.setGradientShadingDVR(not args.no_grad)
     R.updateDt(0.5)

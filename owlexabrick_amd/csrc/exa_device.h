@@ -99,7 +99,7 @@ hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, 
 // refit one height class of internal nodes: box of each child = union below it
 hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
                        const uint8_t *active, hipStream_t s);
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool stats, hipStream_t s);
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool iso, bool stats, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
 hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,

@@ -487,7 +487,37 @@ __device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, cons
 struct SurfaceHit { int primID; float t_hit; V3 Ng; float ambient; V3 baseColor; };
 #define EXA_PRIMID_ISOSURFACE (-23)
 
-// exabrick.cu:1408-1460 traceIsoRay with isoIntegrateBrick (:1187-1256) inlined
+// exabrick.cu:1187-1256 isoIntegrateBrick
+template <bool STATS>
+__device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellValue, IsoResult &ir, float off,
+                                  const Ray &ray, const RegionInfo &ri, float t0, float t1, int numChannels)
+{
+  const float dt = C.a->p.dt * ri.finestLevelCellWidth;
+  float t_i = firstSampleT(t0, dt, off);
+  float t_last = t0;
+  for (int step = 0;; t_i += dt, step++) {
+    if (step >= EXA_MAX_STEPS) { C.guardTripped = true; break; }
+    const float t_next = fminf(t_i, t1);
+    const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
+    t_last = t_next;
+    const V3 pos = ray.org + t_sample * ray.dir;
+    for (int c = 0; c < numChannels; ++c) {
+      float cellValue = 0.f;
+      V3 grad = mk(0.f, 0.f, 0.f);
+      bool doIntegrate;
+      C.count(ST_ISO_EVALS);
+      if (C.a->p.gradientShadingISO) doIntegrate = samplePoint<true, STATS>(C, cellValue, grad, ri, pos, c);
+      else                           doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
+      if (doIntegrate) {
+        isoFunc(C, last_t[c], lastCellValue[c], ray, ir, t_sample, cellValue, ri, c);
+        if (ir.pixelColor.w >= EXA_TERMINATION_THRESHOLD) break;   // leaves the channel loop only
+      }
+    }
+    if (t_next >= t1) break;
+  }
+}
+
+// exabrick.cu:1408-1460 traceIsoRay (LBVH: one closest-region search per segment)
 template <bool STATS>
 __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
 {
@@ -502,7 +532,6 @@ __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
   SurfaceHit result;
   result.primID = -1; result.t_hit = ray.tmax; result.Ng = mk(0.f, 0.f, 0.f);
   result.ambient = 0.f; result.baseColor = mk(0.f, 0.f, 0.f);
-  const int numChannels = C.a->p.numPrimaryChannels;
   for (int seg = 0;; seg++) {
     if (seg >= (1 << 22)) { C.guardTripped = true; break; }
     ray.tmin = alreadyIntegratedDistance;
@@ -514,32 +543,8 @@ __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
     IsoResult ir;
     ir.pixelColor.x = ir.pixelColor.y = ir.pixelColor.z = ir.pixelColor.w = 0.f;
     ir.t_hit = -1.f; ir.gradient = mk(0.f, 0.f, 0.f);
-    {
-      const float t0 = fmaxf(ray.tmin, prd.t0), t1 = fminf(ray.tmax, prd.t1);
-      const float dt = C.a->p.dt * ri.finestLevelCellWidth;
-      float t_i = firstSampleT(t0, dt, off);
-      float t_last = t0;
-      for (int step = 0;; t_i += dt, step++) {
-        if (step >= EXA_MAX_STEPS) { C.guardTripped = true; break; }
-        const float t_next = fminf(t_i, t1);
-        const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
-        t_last = t_next;
-        const V3 pos = ray.org + t_sample * ray.dir;
-        for (int c = 0; c < numChannels; ++c) {
-          float cellValue = 0.f;
-          V3 grad = mk(0.f, 0.f, 0.f);
-          bool doIntegrate;
-          C.count(ST_ISO_EVALS);
-          if (C.a->p.gradientShadingISO) doIntegrate = samplePoint<true, STATS>(C, cellValue, grad, ri, pos, c);
-          else                           doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
-          if (doIntegrate) {
-            isoFunc(C, last_t[c], lastCellValue[c], ray, ir, t_sample, cellValue, ri, c);
-            if (ir.pixelColor.w >= EXA_TERMINATION_THRESHOLD) break;   // leaves the channel loop only
-          }
-        }
-        if (t_next >= t1) break;
-      }
-    }
+    isoIntegrateBrick(C, last_t, lastCellValue, ir, off, ray, ri, fmaxf(ray.tmin, prd.t0), fminf(ray.tmax, prd.t1),
+                      C.a->p.numPrimaryChannels);
     if (ir.t_hit >= 0.f) {
       result.primID = EXA_PRIMID_ISOSURFACE;
       result.t_hit = ir.t_hit / dt_scale;
@@ -794,10 +799,14 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs
 // own walk — instead of one or two lanes at a time whenever a lane's segment ends.
 
 // one step of the walk: pop / descend one level / accept-or-skip a leaf
-template <bool STATS>
+// ISOWALK: the iso march multiplies ray.tmax by dt_scale before every trace (exabrick.cu:1434), so the
+// walk is not clamped at the root; the current tmax clamps t1 at the leaf and ends the walk.
+template <bool ISOWALK, bool STATS>
 __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a,
-                                       float *stackF, int *qRegion, float *qT, const Ray &ray, const int which)
+                                       float *stackF, int *qRegion, float *qT, const Ray &ray, const int which,
+                                       float &walkTmax, const float dtScale)
 {
+  if (ISOWALK && w.ref != EXA_KD_EMPTY && !(w.tn < walkTmax)) { w.ref = EXA_KD_DONE; return; }   // everything left lies beyond tmax
   if (w.ref == EXA_KD_EMPTY || !(w.tf > walkTmin)) { kdPop(C, w, a, stackF); return; }
   if (w.ref < 0) {
     // Leaf.  Its interval [w.tn, w.tf] is max/min over exactly the plane distances the
@@ -808,12 +817,13 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     const int region = ~w.ref;
     C.phase(ST_W_LEAF);
     const float t0 = fmaxf(walkTmin, w.tn);
-    const float t1 = w.tf;
+    const float t1 = ISOWALK ? fminf(walkTmax, w.tf) : w.tf;
     const bool hit = t0 < t1;
     if (STATS) {
       const float4 *rp = reinterpret_cast<const float4 *>(a.regionRec + region);
       const float4 r0 = rp[0], r1 = rp[1];
       Ray rr = ray; rr.tmin = walkTmin;
+      if (ISOWALK) rr.tmax = walkTmax;
       float s0, s1;
       const bool shit = boxTest(rr, mk(r0.x, r0.y, r0.z), mk(r0.w, r1.x, r1.y), s0, s1);
       if (shit != hit || (hit && (s0 != t0 || s1 != t1))) C.st[ST_KD_MISMATCH]++;
@@ -826,7 +836,8 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
       qT[(2 * slot) * 256] = t0;
       qT[(2 * slot + 1) * 256] = t1;
       w.pk.set(PK_QCOUNT, qc + 1);
-      walkTmin = t1 * (1.0000001f);                          // exabrick.cu:1698
+      walkTmin = t1 * (1.0000001f);                          // exabrick.cu:1698 / :1457
+      if (ISOWALK) walkTmax = walkTmax * dtScale;            // the next trace's tmax (:1434)
     }
     w.ref = EXA_KD_EMPTY;
     kdPop(C, w, a, stackF);
@@ -879,7 +890,83 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
   }
 }
 
-template <bool GRAD, bool FAST, bool MULTI, bool STATS>
+// exabrick.cu:1408-1460 traceIsoRay on the kd walk (iso activity bits): segments come out of the
+// ordered walk, one lane at a time refills its own queue here (the iso pre-pass is not the
+// headline path), the march is isoIntegrateBrick.
+template <bool STATS>
+__device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *stackF, int *qRegion, float *qT)
+{
+  const RenderArgs &a = *C.a;
+  const ExaHipFrameState &fs = a.fs;
+  ray.org = xfmPoint(fs, ray.org);
+  ray.dir = xfmVector(fs, ray.dir);
+  const float dt_scale = length(ray.dir);
+  ray.dir = normalize(ray.dir);
+  float walkTmin = dt_scale * ray.tmin;
+  float walkTmax = ray.tmax * dt_scale;                      // tmax of the first trace (:1434)
+  float last_t[EXA_MAX_CHANNELS], lastCellValue[EXA_MAX_CHANNELS];
+  for (int c = 0; c < EXA_MAX_CHANNELS; c++) { last_t[c] = 0.f; lastCellValue[c] = -1e36f; }
+  SurfaceHit result;
+  result.primID = -1; result.t_hit = ray.tmax; result.Ng = mk(0.f, 0.f, 0.f);
+  result.ambient = 0.f; result.baseColor = mk(0.f, 0.f, 0.f);
+  KdWalk w;
+  w.pk.v = 0;
+  {
+    Ray whole = ray; whole.tmin = -INFINITY; whole.tmax = INFINITY;
+    float r0, r1;
+    const bool hit = boxTest(whole, mk(a.kdLo), mk(a.kdHi), r0, r1);
+    w.tn = fmaxf(r0, walkTmin);
+    w.tf = r1;
+    w.tEnd = r1;
+    w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
+  }
+  for (int seg = 0;; seg++) {
+    if (seg >= (1 << 22)) { C.guardTripped = true; break; }
+    for (int g = 0; w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE; g++) {
+      if (g >= (1 << 24)) { C.guardTripped = true; w.ref = EXA_KD_DONE; break; }
+      kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale);
+    }
+    const int qc = w.pk.get(PK_QCOUNT);
+    if (qc == 0) break;
+    const int qh = w.pk.get(PK_QHEAD);
+    const int region = qRegion[qh * 256];
+    const float t0 = qT[(2 * qh) * 256], t1 = qT[(2 * qh + 1) * 256];
+    w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
+    w.pk.set(PK_QCOUNT, qc - 1);
+    C.count(ST_ISO_SEGMENTS);
+    const RegionInfo ri = a.sc.regionInfo[region];
+    IsoResult ir;
+    ir.pixelColor.x = ir.pixelColor.y = ir.pixelColor.z = ir.pixelColor.w = 0.f;
+    ir.t_hit = -1.f; ir.gradient = mk(0.f, 0.f, 0.f);
+    isoIntegrateBrick(C, last_t, lastCellValue, ir, off, ray, ri, t0, t1, a.p.numPrimaryChannels);
+    if (ir.t_hit >= 0.f) {
+      result.primID = EXA_PRIMID_ISOSURFACE;
+      result.t_hit = ir.t_hit / dt_scale;
+      result.Ng = normalize(ir.gradient);
+      result.ambient = 0.f;
+      result.baseColor = mk(ir.pixelColor.x, ir.pixelColor.y, ir.pixelColor.z);
+      return result;
+    }
+  }
+  return result;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd, float *stackF,
+                                                int *qRegion, float *qT)
+{
+  prd.primID = -1;
+  prd.t_hit = ray.tmax;
+  prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
+  bool activeIso = false;
+  for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
+  if (activeIso) {
+    const SurfaceHit isoPRD = traceIsoRayKd(C, ray, 0.f, stackF, qRegion, qT);
+    if (isoPRD.primID == EXA_PRIMID_ISOSURFACE && isoPRD.t_hit < prd.t_hit) prd = isoPRD;
+  }
+}
+
+template <bool GRAD, bool FAST, bool MULTI, bool ISO, bool STATS>
 __global__ __launch_bounds__(256, 6) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -917,8 +1004,50 @@ __global__ __launch_bounds__(256, 6) void renderFrameKdKernel(const RenderArgs a
     ray.org = mk(fs.cam_pos);
     ray.dir = normalize((mk(fs.cam_dir00) + sx * mk(fs.cam_dirDu)) + sy * mk(fs.cam_dirDv));
     ray.tmin = 1e-6f; ray.tmax = 1e8f;
-    const float interleavedSamplingOffset = rnd.next();                           // :1655 (no surfaces: 3rd draw)
-    float surface_t_hit = ray.tmax;                                               // :1657-1659
+    // ---- surfaces first: implicit iso-surface hit, AO rays, background colour (:1601-1652) ----
+    V3 bgColor = mk(0.f, 0.f, 0.f);
+    float surface_t_hit = ray.tmax;
+    if (ISO) {
+      SurfaceHit surface;
+      traceSurfacesKd(C, ray, surface, stackF, qRegion, qT);
+      surface_t_hit = surface.t_hit;
+      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE) {
+        const bool shade = surface.primID >= 0
+                        || (surface.primID == EXA_PRIMID_ISOSURFACE && a.p.gradientShadingISO);
+        if (shade && length(surface.Ng) > 0.f) {
+          const float AO_Radius = fs.ao.length;
+          const int AO_Samples = fs.ao.enabled ? 2 : 0;
+          const V3 isect_pos = ray.org + surface.t_hit * ray.dir;
+          const V3 wN = surface.Ng;
+          const V3 vN = fabsf(wN.x) > fabsf(wN.y) ? normalize(mk(-wN.z, 0.f, wN.x)) : normalize(mk(0.f, wN.z, -wN.y));
+          const V3 uN = cross(vN, wN);
+          int hitCnt = 0;
+          for (int i = 0; i < AO_Samples; ++i) {
+            const float u1 = rnd.next(), u2 = rnd.next();
+            const float r = sqrtf(u1);
+            const float theta = 2.f * 3.14159265358979323846f * u2;
+            const V3 sp = mk(r * cosf(theta), r * sinf(theta), sqrtf(1.f - u1));
+            Ray ao_ray;
+            ao_ray.org = isect_pos;
+            ao_ray.dir = normalize((sp.x * uN + sp.y * vN) + sp.z * wN);
+            ao_ray.tmin = 1e-4f; ao_ray.tmax = AO_Radius;
+            SurfaceHit ao;
+            traceSurfacesKd(C, ao_ray, ao, stackF, qRegion, qT);
+            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE) hitCnt++;
+          }
+          const float shadow = fs.ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
+          const float fd = fabsf(dot(ray.dir, surface.Ng));
+          const float ns = 1.f - shadow;
+          bgColor = mk(surface.ambient + surface.baseColor.x * fd * ns,
+                       surface.ambient + surface.baseColor.y * fd * ns,
+                       surface.ambient + surface.baseColor.z * fd * ns);
+        } else {
+          bgColor = surface.baseColor;
+        }
+      }
+    }
+    const float interleavedSamplingOffset = rnd.next();                           // :1655
+    ray.tmax = surface_t_hit;                                                     // :1657-1659
     if (fs.clipBox.enabled) {
       float c0, c1;
       boxTest(ray, mk(fs.clipBox.lo), mk(fs.clipBox.hi), c0, c1);
@@ -970,7 +1099,7 @@ __global__ __launch_bounds__(256, 6) void renderFrameKdKernel(const RenderArgs a
         for (;;) {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
           if (!__any(want)) break;
-          if (want) kdStep(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0);
+          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f);
         }
       }
       if (!haveSeg) {
@@ -1059,9 +1188,9 @@ __global__ __launch_bounds__(256, 6) void renderFrameKdKernel(const RenderArgs a
       C.count(ST_SAMPLE_EVALS);
     }
 
-    float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * 0.f;           // :1701, bgColor = 0
-    float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * 0.f;
-    float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * 0.f;
+    float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
+    float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
+    float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
     const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
                                        : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
     if (frameID > 0) {
@@ -1084,14 +1213,15 @@ __global__ __launch_bounds__(256, 6) void renderFrameKdKernel(const RenderArgs a
   }
 }
 
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool stats, hipStream_t s)
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool iso, bool stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * 256 * 12;
   const dim3 grid(numBlocks), block(256);
   const bool multi = a.p.numPrimaryChannels > 1;
-#define EXA_LAUNCH(G, F, M, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, S>), grid, block, lds, s, a)
-#define EXA_PICK(G, F, M) do { if (stats) EXA_LAUNCH(G, F, M, true); else EXA_LAUNCH(G, F, M, false); } while (0)
+#define EXA_LAUNCH(G, F, M, I, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S>), grid, block, lds, s, a)
+#define EXA_PICK2(G, F, M, I) do { if (stats) EXA_LAUNCH(G, F, M, I, true); else EXA_LAUNCH(G, F, M, I, false); } while (0)
+#define EXA_PICK(G, F, M) do { if (iso) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
   if (grad) {
     if (fast) { if (multi) EXA_PICK(true, true, true); else EXA_PICK(true, true, false); }
     else      { if (multi) EXA_PICK(true, false, true); else EXA_PICK(true, false, false); }
@@ -1100,6 +1230,7 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
     else      { if (multi) EXA_PICK(false, false, true); else EXA_PICK(false, false, false); }
   }
 #undef EXA_PICK
+#undef EXA_PICK2
 #undef EXA_LAUNCH
   return hipGetLastError();
 }

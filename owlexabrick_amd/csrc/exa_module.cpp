@@ -252,7 +252,7 @@ struct ExaHipRenderer {
                                   active, which, s));
     return 0;
   }
-  bool useKd() const { return haveKd && accel == 1 && !isoEnabled(); }
+  bool useKd() const { return haveKd && accel == 1; }
 
   int refit(DevBuf<BvhNode> &nodes, const uint8_t *active, hipStream_t s)
   {
@@ -324,7 +324,7 @@ struct ExaHipRenderer {
     a.kdRoot = kdRoot;
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
     HIP_TRY(this, hipEventRecord(ev0, s));
-    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, stats, s));
+    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, isoEnabled(), stats, s));
     else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, isoEnabled(), stats, s));
     last.node_bytes = useKd() ? sizeof(KdNodeDev) : sizeof(BvhNode);
     HIP_TRY(this, hipEventRecord(ev1, s));

@@ -49,6 +49,12 @@ CASES = {
     "amr_xfm": lambda: Case(_amr(), W=96, H=96, grad=1,
                             xfm=dict(vx=[48, 0, 0], vy=[0, 48, 0], vz=[0, 0, 32], p=[0, 0, 0]),
                             camera=([0.2, 1.7, 2.0], [0.5, 0.5, 0.5], [0, 1, 0], 60.0)),
+    "amr_xfm_iso": lambda: Case(_amr(), W=96, H=96, grad=1, iso=[(0.45, 0)],
+                                xfm=dict(vx=[48, 0, 0], vy=[0, 48, 0], vz=[0, 0, 32], p=[0, 0, 0]),
+                                camera=([0.2, 1.7, 2.0], [0.5, 0.5, 0.5], [0, 1, 0], 60.0)),
+    "amr_xfm_iso_ao": lambda: Case(_amr(), W=64, H=64, grad=0, iso=[(0.45, 0)], ao=1, ao_length=0.2,
+                                   xfm=dict(vx=[24, 0, 0], vy=[0, 24, 0], vz=[0, 0, 16], p=[1, 2, 3]),
+                                   camera=([-0.3, 2.6, 3.4], [0.9, 0.9, 0.8], [0, 1, 0], 60.0)),
     "amr_inside": lambda: Case(_amr(), W=96, H=96, grad=1, camera=([20.3, 22.1, 14.2], [30, 20, 10], [0, 1, 0], 80.0)),
     "gen_exajet": lambda: Case(scenes.generated(kind="exajet", seed=11, root=(4, 2, 2), B=8, levels=3), W=160, H=96, grad=1),
 }
@@ -63,6 +69,10 @@ def test_hip_matches_oracle(name, accel):
     o = case.run_oracle()
     h = case.run_hip(stats=True)
     r = compare(o, h, name)
+    if case.ao:      # AO directions go through cosf/sinf (libm vs OCML): a few rays may flip hit/miss
+        da = np.abs(o[1] - h[1]).max(axis=-1)
+        assert (da > ACCUM_ATOL).sum() <= max(2, 0.003 * da.size), r
+        return
     assert r["accum_bad"] == 0 and r["rgba_bad"] == 0, r
     assert {k: o[2][k] for k in STAT_KEYS} == {k: h[2][k] for k in STAT_KEYS}   # identical work, sample for sample
     assert h[2]["diag"][8] == 0        # kd interval == the reference's slab test, every leaf
