@@ -206,7 +206,8 @@ def main():
         B = algorithmic_bytes(st, st["pixels"], 0)         # per launch of this rank
         achieved = B / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": "frames/sec at 2048^2 DVR, exajet-like, MI355X", "value": fps, "unit": "frames/s",
+            "metric": f"frames/sec at {W}^2 DVR{'+iso' if args.iso is not None else ''}, {args.config.split('_', 1)[1]}-like, MI355X",
+            "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

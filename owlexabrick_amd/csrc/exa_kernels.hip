@@ -967,7 +967,7 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
 }
 
 template <bool GRAD, bool FAST, bool MULTI, bool ISO, bool STATS>
-__global__ __launch_bounds__(256, 6) void renderFrameKdKernel(const RenderArgs a)
+__global__ __launch_bounds__(256, (ISO ? 3 : (MULTI ? 5 : 6))) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);

@@ -214,8 +214,10 @@ struct Gen {
                   s0 = std::min(1.f, 0.85f * layer * (0.6f + 0.4f * n2) + 0.7f * wk);
                 }
                 fields[0][i] = s0;
+                // further fields: a second quantity living in the same flow features
                 for (int f = 1; f < P.numFields; f++)
-                  fields[f][i] = 0.5f * n1 + 0.5f * valueNoise(x, y, z, 1.f / (0.05f * F.unit), P.seed + 31 * f);
+                  fields[f][i] = std::min(1.f, layer + (inWake ? 0.6f : 0.f))
+                               * (0.5f * n1 + 0.5f * valueNoise(x, y, z, 1.f / (0.05f * F.unit), P.seed + 31 * f));
                 cellIDs[i] = (int32_t)i;
               }
         }
