@@ -59,7 +59,8 @@ struct DeviceScene {
   uint32_t numInternal;            // internal LBVH nodes
 };
 
-enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 4, kSegQueue = 4 };
+enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 4, kSegQueue = 4,
+       kKdBlock = 256 };   // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
 
 enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CORNER_LOADS,
                 ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES,

@@ -779,9 +779,9 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs
     head = head == 0 ? kKdStack - 1 : head - 1;
     w.pk.set(PK_SHEAD, head);
     w.pk.set(PK_SCOUNT, count - 1);
-    w.ref = C.stack[head * 256];
-    w.tn = stackF[(2 * head) * 256];
-    w.tf = stackF[(2 * head + 1) * 256];
+    w.ref = C.stack[head * kKdBlock];
+    w.tn = stackF[(2 * head) * kKdBlock];
+    w.tf = stackF[(2 * head + 1) * kKdBlock];
   } else if (w.pk.get(PK_DROPPED) && w.tf < w.tEnd) {
     w.ref = a.kdRoot;                  // short-stack restart: everything before tf is done
     w.tn = w.tf;
@@ -832,9 +832,9 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
       const int qc = w.pk.get(PK_QCOUNT);
       int slot = w.pk.get(PK_QHEAD) + qc;
       slot = slot >= kSegQueue ? slot - kSegQueue : slot;
-      qRegion[slot * 256] = region;
-      qT[(2 * slot) * 256] = t0;
-      qT[(2 * slot + 1) * 256] = t1;
+      qRegion[slot * kKdBlock] = region;
+      qT[(2 * slot) * kKdBlock] = t0;
+      qT[(2 * slot + 1) * kKdBlock] = t1;
       w.pk.set(PK_QCOUNT, qc + 1);
       walkTmin = t1 * (1.0000001f);                          // exabrick.cu:1698 / :1457
       if (ISOWALK) walkTmax = walkTmax * dtScale;            // the next trace's tmax (:1434)
@@ -874,9 +874,9 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
   } else if (nearAct) {
     if (farAct) {                                            // push far [ts,tf], go near [tn,ts]
       const int head = w.pk.get(PK_SHEAD), count = w.pk.get(PK_SCOUNT);
-      C.stack[head * 256] = farRef;
-      stackF[(2 * head) * 256] = ts;
-      stackF[(2 * head + 1) * 256] = w.tf;
+      C.stack[head * kKdBlock] = farRef;
+      stackF[(2 * head) * kKdBlock] = ts;
+      stackF[(2 * head + 1) * kKdBlock] = w.tf;
       w.pk.set(PK_SHEAD, head == kKdStack - 1 ? 0 : head + 1);
       if (count == kKdStack) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count + 1);
     }
@@ -929,8 +929,8 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
     const int qc = w.pk.get(PK_QCOUNT);
     if (qc == 0) break;
     const int qh = w.pk.get(PK_QHEAD);
-    const int region = qRegion[qh * 256];
-    const float t0 = qT[(2 * qh) * 256], t1 = qT[(2 * qh + 1) * 256];
+    const int region = qRegion[qh * kKdBlock];
+    const float t0 = qT[(2 * qh) * kKdBlock], t1 = qT[(2 * qh + 1) * kKdBlock];
     w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
     w.pk.set(PK_QCOUNT, qc - 1);
     C.count(ST_ISO_SEGMENTS);
@@ -967,16 +967,16 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
 }
 
 template <bool GRAD, bool FAST, bool MULTI, bool ISO, bool STATS>
-__global__ __launch_bounds__(256, (ISO ? 3 : (MULTI ? 5 : 6))) void renderFrameKdKernel(const RenderArgs a)
+__global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
-  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * 256 * 4) + threadIdx.x;
-  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * 256 * 12) + threadIdx.x;
-  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * 256 * 12 + size_t(kSegQueue) * 256 * 4) + threadIdx.x;
-  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += 256) xfLds[i] = a.xf[i];
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
+  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
   Ctx<STATS> C;
@@ -986,9 +986,12 @@ __global__ __launch_bounds__(256, (ISO ? 3 : (MULTI ? 5 : 6))) void renderFrameK
   C.guardTripped = false;
   if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
 
-  const int tile = a.tileMap[blockIdx.x];
+  // a workgroup is kKdBlock/64 waves; each wave renders one 8x8 block of a 16x16 tile
+  const int wavesPerBlock = kKdBlock / 64;
+  const int gwave = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);
+  const int tile = a.tileMap[gwave >> 2];
   const int tx = tile % a.tilesX, ty = tile / a.tilesX;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = gwave & 3, lane = threadIdx.x & 63;
   const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
   const int px = tx * kTile + inX, py = ty * kTile + inY;
   const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
@@ -1107,9 +1110,9 @@ __global__ __launch_bounds__(256, (ISO ? 3 : (MULTI ? 5 : 6))) void renderFrameK
         const int qc = w.pk.get(PK_QCOUNT);
         if (qc == 0) break;                                                        // walk finished: ray done
         const int qh = w.pk.get(PK_QHEAD);
-        const int region = qRegion[qh * 256];
-        const float t0 = qT[(2 * qh) * 256];
-        t1 = qT[(2 * qh + 1) * 256];
+        const int region = qRegion[qh * kKdBlock];
+        const float t0 = qT[(2 * qh) * kKdBlock];
+        t1 = qT[(2 * qh + 1) * kKdBlock];
         w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
         w.pk.set(PK_QCOUNT, qc - 1);
         {
@@ -1216,8 +1219,8 @@ __global__ __launch_bounds__(256, (ISO ? 3 : (MULTI ? 5 : 6))) void renderFrameK
 hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool iso, bool stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
-  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * 256 * 12;
-  const dim3 grid(numBlocks), block(256);
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
+  const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   const bool multi = a.p.numPrimaryChannels > 1;
 #define EXA_LAUNCH(G, F, M, I, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S>), grid, block, lds, s, a)
 #define EXA_PICK2(G, F, M, I) do { if (stats) EXA_LAUNCH(G, F, M, I, true); else EXA_LAUNCH(G, F, M, I, false); } while (0)
