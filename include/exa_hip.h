@@ -211,8 +211,9 @@ int exa_hip_write_accum(ExaHipRenderer *, const float *src4);
  * (programs/exabrick.cu:285-312, 373-402), one byte per region; for tests */
 int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, uint8_t *dst);
 
-/* tuning knobs that never change results: "tile_order" 0 = row-major tile launch
- * order, 1 = XCD-aware supertile order; "accel" 0 = LBVH with restart per segment,
+/* tuning knobs that never change results: "tile_order" = launch sequence of the 16x16 tiles:
+ * 0 row-major, 1 row-major 8x8 supertiles per XCD, 2 pseudo-random, 3 centre-out, 4 Z-order
+ * (default), 5/6/7 Z-order dealt to the XCDs in chunks of 16/64/256 tiles; "accel" 0 = LBVH with restart per segment,
  * 1 = region kd-tree walked front to back (default when the scene carries one).
  * One knob moves results within the stated float tolerance: "fast_math" 1 (default)
  * evaluates the opacity correction powf as exp2(dt*log2(x)) on the hardware

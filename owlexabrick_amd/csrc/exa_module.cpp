@@ -188,7 +188,7 @@ struct ExaHipRenderer {
   // framebuffer / shard
   int W = 0, H = 0, tilesX = 0, tilesY = 0;
   int rank = 0, world = 1;
-  int tileOrder = 0;
+  int tileOrder = 4;                 // Z-order launch sequence (measured best on C4)
   int debugPixel = -1;
   int ablate = 0;
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
@@ -238,6 +238,34 @@ struct ExaHipRenderer {
         const int super = (j / 64) * 8 + xcd, in = j % 64;
         const int sx = super % stx, sy = super / stx;
         map[b] = (sy * 8 + in / 8) * tilesX + sx * 8 + in % 8;
+      }
+    }
+    if (tileOrder == 2) {          // fixed pseudo-random permutation (load-balance experiment)
+      uint64_t st = 0x9E3779B97F4A7C15ull;
+      for (size_t i = map.size(); i > 1; i--) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        std::swap(map[i - 1], map[size_t((st >> 33) % i)]);
+      }
+    } else if (tileOrder == 3) {   // centre-out: tiles nearest the image centre first
+      const float cx = 0.5f * tilesX, cy = 0.5f * tilesY;
+      std::stable_sort(map.begin(), map.end(), [&](int32_t a, int32_t b) {
+        const float ax = a % tilesX + 0.5f - cx, ay = a / tilesX + 0.5f - cy, bx = b % tilesX + 0.5f - cx, by = b / tilesX + 0.5f - cy;
+        return ax * ax + ay * ay < bx * bx + by * by;
+      });
+    }
+    if (tileOrder >= 4) {          // Z-order: tiles in flight form a compact 2-d patch of the image
+      auto part = [](uint32_t v) { v &= 0xffff; v = (v | v << 8) & 0x00ff00ff; v = (v | v << 4) & 0x0f0f0f0f; v = (v | v << 2) & 0x33333333; v = (v | v << 1) & 0x55555555; return v; };
+      std::stable_sort(map.begin(), map.end(), [&](int32_t a, int32_t b) {
+        return (part(a % tilesX) | part(a / tilesX) << 1) < (part(b % tilesX) | part(b / tilesX) << 1);
+      });
+      // 5..7: deal chunks of 16/64/256 Z-consecutive tiles to the 8 XCDs (block b runs on XCD b%8)
+      const int chunk = tileOrder == 5 ? 16 : (tileOrder == 6 ? 64 : (tileOrder == 7 ? 256 : 0));
+      if (chunk && map.size() % size_t(8 * chunk) == 0) {
+        std::vector<int32_t> z(map);
+        for (size_t b = 0; b < map.size(); b++) {
+          const size_t xcd = b % 8, j = b / 8;
+          map[b] = z[((j / chunk) * 8 + xcd) * chunk + j % chunk];
+        }
       }
     }
     HIP_TRY(this, tileMap.upload(map.data(), map.size()));

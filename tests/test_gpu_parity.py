@@ -224,10 +224,11 @@ def test_full_frame_properties_at_benchmark_size():
     R.setOption("fast_math", 1)
     a = R.render()
     assert np.abs(harness.unpack_rgba8(a).astype(int) - harness.unpack_rgba8(lb).astype(int)).max() <= 6
-    R.setOption("tile_order", 1)
-    R.resizeFrameBuffer((2048, 2048))
-    b = R.render()
-    assert np.array_equal(a, b)                               # launch order never changes pixels
+    for order in (1, 4, 5):
+        R.setOption("tile_order", order)
+        R.resizeFrameBuffer((2048, 2048))
+        b = R.render()
+        assert np.array_equal(a, b)                           # launch order never changes pixels
     acc_skip = R.readAccum()
     R.setSpaceSkipping(False)
     c = R.render()
