@@ -89,7 +89,6 @@ struct RenderArgs {
   unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
   int32_t           *errorFlag;     // set when a loop guard trips
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
-  int32_t            ablate;        // timing experiments only (wrong pixels): 1 skip integrateVolume, 2 skip basis
 };
 
 // ---- launchers implemented in exa_kernels.hip ----

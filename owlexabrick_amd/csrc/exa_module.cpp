@@ -190,7 +190,6 @@ struct ExaHipRenderer {
   int rank = 0, world = 1;
   int tileOrder = 4;                 // Z-order launch sequence (measured best on C4)
   int debugPixel = -1;
-  int ablate = 0;
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
   DevBuf<float4> accum;
   DevBuf<uint32_t> color;
@@ -346,7 +345,6 @@ struct ExaHipRenderer {
     a.stats = statsBuf.p;
     a.errorFlag = errorFlag.p;
     a.debugPixel = debugPixel;
-    a.ablate = ablate;
     a.kdNodes = kdNodes.p;
     a.regionRec = regionRec.p;
     a.kdRoot = kdRoot;
@@ -604,7 +602,6 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
-  if (!std::strcmp(key, "ablate")) { h->ablate = value; return 0; }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
   h->fail(std::string("exa_hip_set_option: unknown key ") + key);
   return 1;
