@@ -898,12 +898,136 @@ static SurfacePRD trace_iso_ray(Ctx *C, Ray ray, float off)
   return result;
 }
 
-/* exabrick.cu:1475-1529 traceSurfaces — only the implicit-iso branch is on the
- * hot path (meshes, contour planes and streamlines are SURVEY 8f rows). */
-static void trace_surfaces(Ctx *C, Ray ray, SurfacePRD *prd)
+/* ------------------------------------------------------------------ */
+/* contour planes                                   */
+/* ------------------------------------------------------------------ */
+#define PRIMID_PLANE (-24)
+
+/* exabrick.cu:1267-1284 */
+static float intersect_line_plane(v3 p1, v3 p2, v3 normal, float offset)
+{
+  float s = vdot(normal, vnormalize(vsub(p2, p1)));
+  if (s == 0.f) return -1.f;
+  float t = (offset - vdot(normal, p1)) / s;
+  if (t < 0.f || t > vlength(vsub(p2, p1))) return -1.f;
+  return t;
+}
+
+/* exabrick.cu:1287-1314 */
+static void intersect_box_plane(v3 blo, v3 bhi, v3 normal, float offset, v3 *pts, int *isectCnt)
+{
+  static const int key[4][3] = { {0,0,0}, {1,0,1}, {1,1,0}, {0,1,1} };
+  const v3 corners[2] = { blo, bhi };
+  *isectCnt = 0;
+  for (int i = 0; i < 4 && *isectCnt < 6; ++i) {
+    for (int j = 0; j < 3 && *isectCnt < 6; ++j) {
+      v3 p1 = V3((j == 0) ? corners[1 - key[i][0]].x : corners[key[i][0]].x,
+                 (j == 1) ? corners[1 - key[i][1]].y : corners[key[i][1]].y,
+                 (j == 2) ? corners[1 - key[i][2]].z : corners[key[i][2]].z);
+      v3 p2 = V3(corners[key[i][0]].x, corners[key[i][1]].y, corners[key[i][2]].z);
+      float t = intersect_line_plane(p1, p2, normal, offset);
+      if (t >= 0.f) pts[(*isectCnt)++] = vadd(p1, vscale(t, vnormalize(vsub(p2, p1))));
+    }
+  }
+}
+
+/* exabrick.cu:1316-1343 */
+static float intersect_ray_triangle(const Ray *ray, v3 v1, v3 e1, v3 e2)
+{
+  v3 s1 = vcross(ray->dir, e2);
+  float div = vdot(s1, e1);
+  if (div == 0.f) return -1.f;
+  float invDiv = 1.f / div;
+  v3 d = vsub(ray->org, v1);
+  float b1 = vdot(d, s1) * invDiv;
+  if (b1 < 0.f || b1 > 1.f) return -1.f;
+  v3 s2 = vcross(d, e1);
+  float b2 = vdot(ray->dir, s2) * invDiv;
+  if (b2 < 0.f || b1 + b2 > 1.f) return -1.f;
+  return vdot(e2, s2) * invDiv;
+}
+
+/* exabrick.cu:818-830 samplePointWithInfRay.  The reference indexes region[-1] when the
+ * degenerate ray hits nothing (undefined); here that case yields 0 and the sample is skipped. */
+static float sample_point_with_inf_ray(Ctx *C, v3 pos, int channel)
+{
+  Ray ray = { pos, V3(1.f, 1.f, 1.f), 0.f, 2e-10f };
+  RegionHit prd = trace_region(C->S, C->volActive, &ray);
+  float value = 0.f;
+  if (prd.leafID >= 0) sample_point(C, &value, prd.leafID, pos, channel);
+  return value;
+}
+
+/* rcp(affine3f) of the un-vendored owl: inverse of the linear part by adjoint/determinant */
+static void world_space_bounds(const OrScene *S, const OrFrameState *fs, v3 *wlo, v3 *whi)
+{
+  v3 vx = vfrom(fs->xfm_vx), vy = vfrom(fs->xfm_vy), vz = vfrom(fs->xfm_vz), p = vfrom(fs->xfm_p);
+  v3 c0 = vcross(vy, vz), c1 = vcross(vz, vx), c2 = vcross(vx, vy);
+  float det = vdot(vx, c0);
+  v3 ix = V3(c0.x / det, c1.x / det, c2.x / det);
+  v3 iy = V3(c0.y / det, c1.y / det, c2.y / det);
+  v3 iz = V3(c0.z / det, c1.z / det, c2.z / det);
+  v3 ip = vneg(vadd(vscale(p.x, ix), vadd(vscale(p.y, iy), vscale(p.z, iz))));
+  v3 lo = vfrom(S->vb_lo), hi = vfrom(S->vb_hi);               /* OptixRenderer.cpp:330-332 */
+  *wlo = vadd(vscale(lo.x, ix), vadd(vscale(lo.y, iy), vadd(vscale(lo.z, iz), ip)));
+  *whi = vadd(vscale(hi.x, ix), vadd(vscale(hi.y, iy), vadd(vscale(hi.z, iz), ip)));
+}
+
+/* exabrick.cu:1345-1406 traceContourRay */
+static SurfacePRD trace_contour_ray(Ctx *C, Ray ray, v3 normal, float offset, int channel)
+{
+  SurfacePRD prd; memset(&prd, 0, sizeof(prd));
+  prd.primID = -1;      /* left uninitialised by the reference when the plane is missed */
+  prd.t_hit = ray.tmax;
+  v3 pts[6];
+  int isectCnt;
+  intersect_box_plane(V3(0.f, 0.f, 0.f), V3(1.f, 1.f, 1.f), normal, offset, pts, &isectCnt);
+  v3 wlo, whi;
+  world_space_bounds(C->S, C->fs, &wlo, &whi);
+  for (int i = 0; i < isectCnt; ++i) {                          /* scale to world bounds :1359-1362 */
+    pts[i] = vmul(pts[i], vsub(whi, wlo));
+    pts[i] = vadd(pts[i], wlo);
+  }
+  float t = -1.f;
+  for (int i = 0; i < isectCnt - 1; ++i) {                      /* cyclical selection sort :1367-1382 */
+    int minIdx = i;
+    for (int j = i + 1; j < isectCnt; ++j) {
+      v3 v = vcross(vsub(pts[j], pts[0]), vsub(pts[minIdx], pts[0]));
+      if (vdot(v, normal) < 0.f) minIdx = j;
+    }
+    v3 tmp = pts[i]; pts[i] = pts[minIdx]; pts[minIdx] = tmp;
+  }
+  for (int i = 2; i < isectCnt; ++i) {                          /* fan :1384-1391 */
+    v3 v1 = pts[0], e1 = vsub(pts[i - 1], v1), e2 = vsub(pts[i], v1);
+    float tt = intersect_ray_triangle(&ray, v1, e1, e2);
+    if (tt >= 0.f && (tt < t || t < 0.f)) t = tt;
+  }
+  if (t < 0.f) return prd;
+  float value = sample_point_with_inf_ray(C, vadd(ray.org, vscale(t, ray.dir)), 0);   /* :1396, channel 0 */
+  v4 sample = lookup_xf(C->S, C->fs, value, channel);
+  prd.primID = PRIMID_PLANE;
+  prd.t_hit = t;
+  prd.Ng = normal;
+  prd.ambient = 0.f;
+  prd.baseColor = V3(sample.x, sample.y, sample.z);
+  return prd;
+}
+
+/* exabrick.cu:1475-1529 traceSurfaces: contour planes and implicit iso-surfaces (meshes and
+ * streamlines are SURVEY 8f rank 4) */
+static void trace_surfaces(Ctx *C, Ray ray, SurfacePRD *prd, int withContourPlanes)
 {
   prd->primID = -1;
   prd->t_hit = ray.tmax;
+  if (withContourPlanes) {
+    for (int i = 0; i < OR_MAX_CONTOUR_PLANES; ++i) {
+      if (C->fs->contour[i].enabled) {
+        SurfacePRD contourPRD = trace_contour_ray(C, ray, vfrom(C->fs->contour[i].normal),
+                                                  C->fs->contour[i].offset, C->fs->contour[i].channel);
+        if (contourPRD.primID == PRIMID_PLANE && contourPRD.t_hit < prd->t_hit) *prd = contourPRD;
+      }
+    }
+  }
   int activeIsoSurfaces = 0;
   for (int i = 0; i < OR_MAX_ISO_SURFACES; i++) activeIsoSurfaces |= C->fs->iso[i].enabled;
   if (activeIsoSurfaces) {
@@ -942,11 +1066,11 @@ static void render_pixel(Ctx *C, int px, int py, int W, int H, uint32_t *rgba, f
   ray.tmin = 1e-6f; ray.tmax = 1e8f;
 
   SurfacePRD surface; memset(&surface, 0, sizeof(surface));
-  trace_surfaces(C, ray, &surface);                                          /* :1601 */
+  trace_surfaces(C, ray, &surface, 1);                                       /* :1601 ST_ALL_SURFACES */
 
   v3 bgColor = v3s(0.f);
-  if (surface.primID >= 0 || surface.primID == PRIMID_ISOSURFACE) {          /* :1604 */
-    const int shade = surface.primID >= 0
+  if (surface.primID >= 0 || surface.primID == PRIMID_ISOSURFACE || surface.primID == PRIMID_PLANE) { /* :1604 */
+    const int shade = surface.primID >= 0 || surface.primID == PRIMID_PLANE
                    || (surface.primID == PRIMID_ISOSURFACE && C->P->gradientShadingISO);
     if (shade && vlength(surface.Ng) > 0.f) {
       const float AO_Radius = fs->ao.length;
@@ -961,8 +1085,8 @@ static void render_pixel(Ctx *C, int px, int py, int W, int H, uint32_t *rgba, f
         v3 dir = vnormalize(vadd(vadd(vscale(sp.x, u), vscale(sp.y, v)), vscale(sp.z, w)));
         Ray ao_ray = {isect_pos, dir, 1e-4f, AO_Radius};
         SurfacePRD ao;
-        trace_surfaces(C, ao_ray, &ao);
-        if (ao.primID >= 0 || ao.primID == PRIMID_ISOSURFACE) hitCnt++;
+        trace_surfaces(C, ao_ray, &ao, 0);                                   /* :1637-1639 no contour planes */
+        if (ao.primID >= 0 || ao.primID == PRIMID_ISOSURFACE || ao.primID == PRIMID_PLANE) hitCnt++;
       }
       float shadow = fs->ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
       /* :1646-1648  ambient + baseColor*fabs(dot(dir,Ng))*(1-shadow), left to right */

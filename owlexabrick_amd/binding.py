@@ -232,6 +232,16 @@ class Renderer:
             self.frameState.iso[i].channel = int(channels[i])
             self.frameState.iso[i].enabled = int(enabled[i])
 
+    def updateContourPlanes(self, normals, offsets, channels, enabled):
+        for i in range(MAX_CONTOUR):
+            n = np.asarray(normals[i], dtype=np.float32)
+            n = (n * (np.float32(1.0) / np.sqrt(np.dot(n, n), dtype=np.float32))).astype(np.float32)   # normalize() (:511)
+            for k in range(3):
+                self.frameState.contour[i].normal[k] = float(n[k])
+            self.frameState.contour[i].offset = float(offsets[i])
+            self.frameState.contour[i].channel = int(channels[i])
+            self.frameState.contour[i].enabled = int(enabled[i])
+
     def updateCamera(self, pos, dir00, dirDu, dirDv):
         for i in range(3):
             self.frameState.cam_pos[i], self.frameState.cam_dir00[i] = float(pos[i]), float(dir00[i])

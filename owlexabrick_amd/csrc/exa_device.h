@@ -77,6 +77,7 @@ struct RenderArgs {
   const RegionRec   *regionRec;
   int32_t            kdRoot;
   float              kdLo[3], kdHi[3];   // box of the kd root = union of all brick domains
+  float              worldLo[3], worldHi[3];   // worldSpaceBounds (OptixRenderer.cpp:330-332), contour planes
   ExaHipFrameState   fs;
   ExaHipParams       p;
   const float4      *xf;            // numXfChannels x 128 (r,g,b,a)

@@ -487,6 +487,92 @@ __device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, cons
 struct SurfaceHit { int primID; float t_hit; V3 Ng; float ambient; V3 baseColor; };
 #define EXA_PRIMID_ISOSURFACE (-23)
 
+// ------------------------------------------------------------------------
+// contour planes (exabrick.cu:1267-1406)
+// ------------------------------------------------------------------------
+#define EXA_PRIMID_PLANE (-24)
+
+__device__ __forceinline__ float intersectLinePlane(V3 p1, V3 p2, V3 normal, float offset)      // :1267-1284
+{
+  const float s = dot(normal, normalize(p2 - p1));
+  if (s == 0.f) return -1.f;
+  const float t = (offset - dot(normal, p1)) / s;
+  if (t < 0.f || t > length(p2 - p1)) return -1.f;
+  return t;
+}
+
+__device__ __forceinline__ float intersectRayTriangle(const Ray &ray, V3 v1, V3 e1, V3 e2)      // :1316-1343
+{
+  const V3 s1 = cross(ray.dir, e2);
+  const float div = dot(s1, e1);
+  if (div == 0.f) return -1.f;
+  const float invDiv = 1.f / div;
+  const V3 d = ray.org - v1;
+  const float b1 = dot(d, s1) * invDiv;
+  if (b1 < 0.f || b1 > 1.f) return -1.f;
+  const V3 s2 = cross(d, e1);
+  const float b2 = dot(ray.dir, s2) * invDiv;
+  if (b2 < 0.f || b1 + b2 > 1.f) return -1.f;
+  return dot(e2, s2) * invDiv;
+}
+
+// traceContourRay (:1345-1406).  findRegion(pos) is the degenerate trace of samplePointWithInfRay
+// (:818-830: origin pos, direction (1,1,1), [0, 2e-10]) on whichever structure the kernel walks;
+// the reference reads region[-1] when it misses, here the sample is skipped (value 0).
+template <bool STATS, class FindRegion>
+__device__ SurfaceHit traceContourRay(Ctx<STATS> &C, const Ray &ray, V3 normal, float offset, int channel, FindRegion findRegion)
+{
+  SurfaceHit prd;
+  prd.primID = -1; prd.t_hit = ray.tmax; prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
+  V3 pts[6];
+  int isectCnt = 0;
+  {                                                                 // intersectBoxPlane on the unit box (:1287-1314)
+    const int key[4][3] = { {0,0,0}, {1,0,1}, {1,1,0}, {0,1,1} };
+    for (int i = 0; i < 4 && isectCnt < 6; ++i)
+      for (int j = 0; j < 3 && isectCnt < 6; ++j) {
+        const V3 p1 = mk(float(j == 0 ? 1 - key[i][0] : key[i][0]), float(j == 1 ? 1 - key[i][1] : key[i][1]),
+                         float(j == 2 ? 1 - key[i][2] : key[i][2]));
+        const V3 p2 = mk(float(key[i][0]), float(key[i][1]), float(key[i][2]));
+        const float t = intersectLinePlane(p1, p2, normal, offset);
+        if (t >= 0.f) pts[isectCnt++] = p1 + t * normalize(p2 - p1);
+      }
+  }
+  const V3 wlo = mk(C.a->worldLo), whi = mk(C.a->worldHi);
+  for (int i = 0; i < isectCnt; ++i) {                              // scale to world bounds (:1359-1362)
+    const V3 sz = whi - wlo;
+    pts[i] = mk(pts[i].x * sz.x, pts[i].y * sz.y, pts[i].z * sz.z) + wlo;
+  }
+  float t = -1.f;
+  for (int i = 0; i < isectCnt - 1; ++i) {                          // cyclical selection sort (:1367-1382)
+    int minIdx = i;
+    for (int j = i + 1; j < isectCnt; ++j) {
+      const V3 v = cross(pts[j] - pts[0], pts[minIdx] - pts[0]);
+      if (dot(v, normal) < 0.f) minIdx = j;
+    }
+    const V3 tmp = pts[i]; pts[i] = pts[minIdx]; pts[minIdx] = tmp;
+  }
+  for (int i = 2; i < isectCnt; ++i) {                              // triangle fan (:1384-1391)
+    const V3 v1 = pts[0], e1 = pts[i - 1] - v1, e2 = pts[i] - v1;
+    const float tt = intersectRayTriangle(ray, v1, e1, e2);
+    if (tt >= 0.f && (tt < t || t < 0.f)) t = tt;
+  }
+  if (t < 0.f) return prd;
+  const V3 pos = ray.org + t * ray.dir;
+  float value = 0.f;
+  const int region = findRegion(pos);
+  if (region >= 0) {
+    V3 unused;
+    samplePoint<false, STATS>(C, value, unused, C.a->sc.regionInfo[region], pos, 0);   // :1396, channel 0
+  }
+  const Color4 sample = lookupXF(C.xfLds, C.a->fs, value, channel);
+  prd.primID = EXA_PRIMID_PLANE;
+  prd.t_hit = t;
+  prd.Ng = normal;
+  prd.ambient = 0.f;
+  prd.baseColor = mk(sample.x, sample.y, sample.z);
+  return prd;
+}
+
 // exabrick.cu:1187-1256 isoIntegrateBrick
 template <bool STATS>
 __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellValue, IsoResult &ir, float off,
@@ -558,13 +644,25 @@ __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
   return result;
 }
 
-// exabrick.cu:1475-1529 traceSurfaces, implicit-iso branch
+// exabrick.cu:1475-1529 traceSurfaces: contour planes, then implicit iso-surfaces
 template <bool STATS>
-__device__ __forceinline__ void traceSurfaces(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
+__device__ __forceinline__ void traceSurfaces(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd, bool withContourPlanes)
 {
   prd.primID = -1;
   prd.t_hit = ray.tmax;
   prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
+  if (withContourPlanes) {
+    for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; ++i)
+      if (C.a->fs.contour[i].enabled) {
+        auto find = [&](V3 pos) {
+          Ray r; r.org = pos; r.dir = mk(1.f, 1.f, 1.f); r.tmin = 0.f; r.tmax = 2e-10f;
+          return traceRegion(C, C.a->volNodes, r).leafID;
+        };
+        const SurfaceHit c = traceContourRay(C, ray, mk(C.a->fs.contour[i].normal), C.a->fs.contour[i].offset,
+                                             C.a->fs.contour[i].channel, find);
+        if (c.primID == EXA_PRIMID_PLANE && c.t_hit < prd.t_hit) prd = c;
+      }
+  }
   bool activeIso = false;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
   if (activeIso) {
@@ -617,9 +715,9 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
     surface.Ng = mk(0.f, 0.f, 0.f); surface.ambient = 0.f; surface.baseColor = mk(0.f, 0.f, 0.f);
     V3 bgColor = mk(0.f, 0.f, 0.f);
     if (ISO) {
-      traceSurfaces(C, ray, surface);                                             // :1601
-      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE) {      // :1604-1652
-        const bool shade = surface.primID >= 0
+      traceSurfaces(C, ray, surface, true);                                       // :1601
+      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE || surface.primID == EXA_PRIMID_PLANE) {   // :1604-1652
+        const bool shade = surface.primID >= 0 || surface.primID == EXA_PRIMID_PLANE
                         || (surface.primID == EXA_PRIMID_ISOSURFACE && a.p.gradientShadingISO);
         if (shade && length(surface.Ng) > 0.f) {
           const float AO_Radius = fs.ao.length;
@@ -639,8 +737,8 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
             ao_ray.dir = normalize((sp.x * u + sp.y * v) + sp.z * w);
             ao_ray.tmin = 1e-4f; ao_ray.tmax = AO_Radius;
             SurfaceHit ao;
-            traceSurfaces(C, ao_ray, ao);
-            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE) hitCnt++;
+            traceSurfaces(C, ao_ray, ao, false);
+            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE) hitCnt++;
           }
           const float shadow = fs.ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
           const float fd = fabsf(dot(ray.dir, surface.Ng));
@@ -951,13 +1049,46 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
   return result;
 }
 
+// samplePointWithInfRay's degenerate trace on the kd walk: first accepted leaf of the ray
+// (pos, (1,1,1), [0, 2e-10]) under the volume activity bits
 template <bool STATS>
-__device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd, float *stackF,
-                                                int *qRegion, float *qT)
+__device__ int kdFindRegion(Ctx<STATS> &C, V3 pos, float *stackF, int *qRegion, float *qT)
+{
+  const RenderArgs &a = *C.a;
+  Ray ray; ray.org = pos; ray.dir = mk(1.f, 1.f, 1.f); ray.tmin = 0.f; ray.tmax = 2e-10f;
+  KdWalk w;
+  w.pk.v = 0;
+  Ray whole = ray; whole.tmin = -INFINITY; whole.tmax = INFINITY;
+  float r0, r1;
+  const bool hit = boxTest(whole, mk(a.kdLo), mk(a.kdHi), r0, r1);
+  w.tn = fmaxf(r0, ray.tmin);
+  w.tf = fminf(r1, ray.tmax);
+  w.tEnd = w.tf;
+  w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
+  float walkTmin = ray.tmin;
+  for (int g = 0; w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE; g++) {
+    if (g >= (1 << 24)) { C.guardTripped = true; break; }
+    kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f);
+  }
+  return w.pk.get(PK_QCOUNT) ? qRegion[w.pk.get(PK_QHEAD) * kKdBlock] : -1;
+}
+
+template <bool STATS>
+__device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd, bool withContourPlanes,
+                                                float *stackF, int *qRegion, float *qT)
 {
   prd.primID = -1;
   prd.t_hit = ray.tmax;
   prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
+  if (withContourPlanes) {
+    for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; ++i)
+      if (C.a->fs.contour[i].enabled) {
+        auto find = [&](V3 pos) { return kdFindRegion(C, pos, stackF, qRegion, qT); };
+        const SurfaceHit c = traceContourRay(C, ray, mk(C.a->fs.contour[i].normal), C.a->fs.contour[i].offset,
+                                             C.a->fs.contour[i].channel, find);
+        if (c.primID == EXA_PRIMID_PLANE && c.t_hit < prd.t_hit) prd = c;
+      }
+  }
   bool activeIso = false;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
   if (activeIso) {
@@ -1012,10 +1143,10 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
     float surface_t_hit = ray.tmax;
     if (ISO) {
       SurfaceHit surface;
-      traceSurfacesKd(C, ray, surface, stackF, qRegion, qT);
+      traceSurfacesKd(C, ray, surface, true, stackF, qRegion, qT);
       surface_t_hit = surface.t_hit;
-      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE) {
-        const bool shade = surface.primID >= 0
+      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE || surface.primID == EXA_PRIMID_PLANE) {
+        const bool shade = surface.primID >= 0 || surface.primID == EXA_PRIMID_PLANE
                         || (surface.primID == EXA_PRIMID_ISOSURFACE && a.p.gradientShadingISO);
         if (shade && length(surface.Ng) > 0.f) {
           const float AO_Radius = fs.ao.length;
@@ -1035,8 +1166,8 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
             ao_ray.dir = normalize((sp.x * uN + sp.y * vN) + sp.z * wN);
             ao_ray.tmin = 1e-4f; ao_ray.tmax = AO_Radius;
             SurfaceHit ao;
-            traceSurfacesKd(C, ao_ray, ao, stackF, qRegion, qT);
-            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE) hitCnt++;
+            traceSurfacesKd(C, ao_ray, ao, false, stackF, qRegion, qT);
+            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE) hitCnt++;
           }
           const float shadow = fs.ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
           const float fd = fabsf(dot(ray.dir, surface.Ng));

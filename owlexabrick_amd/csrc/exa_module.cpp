@@ -207,6 +207,30 @@ struct ExaHipRenderer {
     for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) if (fs.iso[i].enabled) return true;
     return false;
   }
+  bool contourEnabled() const
+  {
+    for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; i++) if (fs.contour[i].enabled) return true;
+    return false;
+  }
+  bool surfacesEnabled() const { return isoEnabled() || contourEnabled(); }
+  float voxLo[3], voxHi[3];
+  // worldSpaceBounds = rcp(voxelSpaceTransform) applied to the voxel bounds (OptixRenderer.cpp:330-332);
+  // rcp(affine3f) = inverse of the linear part by adjoint/determinant, p' = -(L^-1 p)
+  void worldBounds(float lo[3], float hi[3]) const
+  {
+    auto cross = [](const float *a, const float *b, float *o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; };
+    float c0[3], c1[3], c2[3];
+    cross(fs.xfm_vy, fs.xfm_vz, c0); cross(fs.xfm_vz, fs.xfm_vx, c1); cross(fs.xfm_vx, fs.xfm_vy, c2);
+    const float det = fs.xfm_vx[0] * c0[0] + fs.xfm_vx[1] * c0[1] + fs.xfm_vx[2] * c0[2];
+    const float ix[3] = { c0[0] / det, c1[0] / det, c2[0] / det }, iy[3] = { c0[1] / det, c1[1] / det, c2[1] / det },
+                iz[3] = { c0[2] / det, c1[2] / det, c2[2] / det };
+    float ip[3];
+    for (int k = 0; k < 3; k++) ip[k] = -(fs.xfm_p[0] * ix[k] + (fs.xfm_p[1] * iy[k] + fs.xfm_p[2] * iz[k]));
+    for (int k = 0; k < 3; k++) {
+      lo[k] = voxLo[0] * ix[k] + (voxLo[1] * iy[k] + (voxLo[2] * iz[k] + ip[k]));
+      hi[k] = voxHi[0] * ix[k] + (voxHi[1] * iy[k] + (voxHi[2] * iz[k] + ip[k]));
+    }
+  }
   uint64_t outputPixels() const { return uint64_t(numBlocksFor()) * kTilePixels; }
   int numBlocksFor() const
   {
@@ -349,9 +373,10 @@ struct ExaHipRenderer {
     a.regionRec = regionRec.p;
     a.kdRoot = kdRoot;
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
+    worldBounds(a.worldLo, a.worldHi);
     HIP_TRY(this, hipEventRecord(ev0, s));
-    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, isoEnabled(), stats, s));
-    else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, isoEnabled(), stats, s));
+    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfacesEnabled(), stats, s));
+    else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, surfacesEnabled(), stats, s));
     last.node_bytes = useKd() ? sizeof(KdNodeDev) : sizeof(BvhNode);
     HIP_TRY(this, hipEventRecord(ev1, s));
     return 0;
@@ -396,6 +421,7 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
     if (scene->channelOffset[f] + scene->totalCells > uint64_t(scene->numFields) * scene->totalCells) { h->fail("exa_hip_create: channel offset out of range"); return bail(); }
 
   h->numFields = scene->numFields;
+  for (int k = 0; k < 3; k++) { h->voxLo[k] = scene->voxelBounds_lo[k]; h->voxHi[k] = scene->voxelBounds_hi[k]; }
   static_assert(sizeof(ExaBrick) == 2 * sizeof(int4), "brick = two int4");
   CREATE_TRY(h->bricks.upload(reinterpret_cast<const int4 *>(scene->bricks), scene->numBricks * 2));
   CREATE_TRY(h->leafList.upload(scene->leafList, scene->leafListSize));

@@ -75,7 +75,7 @@ def default_settings():
 
 
 def fill_frame_state(fs, cam, xf_domains, xfOpacityScale=1.0, frameID=0, iso=None, clip=None,
-                     ao_enabled=0, ao_length=1e20, xfm=None):
+                     ao_enabled=0, ao_length=1e20, xfm=None, contour=None):
     """fill a ctypes FrameState-like struct (oracle's or the C ABI's — same field names)."""
     for k, dst in (("pos", fs.cam_pos), ("dir00", fs.cam_dir00), ("dirDu", fs.cam_dirDu), ("dirDv", fs.cam_dirDv)):
         for i in range(3):
@@ -88,6 +88,11 @@ def fill_frame_state(fs, cam, xf_domains, xfOpacityScale=1.0, frameID=0, iso=Non
         fs.contour[i].enabled = 0
         fs.contour[i].normal[0], fs.contour[i].normal[1], fs.contour[i].normal[2] = 1.0, 0.0, 0.0
         fs.contour[i].channel, fs.contour[i].offset = 0, 0.5
+    for i, (normal, offset, channel) in enumerate(contour or []):
+        n = _normalize(normal)            # OptixRenderer::updateContourPlanes normalises (OptixRenderer.cpp:511)
+        fs.contour[i].enabled = 1
+        fs.contour[i].normal[0], fs.contour[i].normal[1], fs.contour[i].normal[2] = float(n[0]), float(n[1]), float(n[2])
+        fs.contour[i].channel, fs.contour[i].offset = int(channel), float(offset)
     fs.clipBox.enabled = 0
     if clip is not None:
         fs.clipBox.enabled = 1

@@ -30,7 +30,7 @@ def band_xf(lo=0.35, hi=0.65):
 class Case:
     def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
                  space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
-                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None):
+                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None, contour=None):
         self.scene, self.W, self.H = scene, W, H
         self.grad, self.iso, self.dt = grad, iso, dt
         self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
@@ -39,6 +39,7 @@ class Case:
         self.camera, self.xfm, self.grad_iso, self.multi = camera, xfm, grad_iso, multi
         self.accel = accel
         self.fast_math = fast_math
+        self.contour = contour
         nf = len(scene.fields)
         self.nprim = nf if multi else 1
         self.colormap_channel = 0 if (multi or nf < 2) else 1
@@ -71,9 +72,10 @@ class Case:
         fs = po.FrameState()
         harness.fill_frame_state(fs, self.cam(lo, hi), self.xf_domains, xfOpacityScale=self.opacity_scale,
                                  frameID=self.frameID if frameID is None else frameID, iso=self.iso,
-                                 clip=self.clip, ao_enabled=self.ao, ao_length=self.ao_length, xfm=self.xfm)
-        P = po.Params(self.dt, self.nprim, self.colormap_channel, self.grad, self.grad_iso, self.nprim,
-                      self.space_skipping)
+                                 clip=self.clip, ao_enabled=self.ao, ao_length=self.ao_length, xfm=self.xfm,
+                                 contour=self.contour)
+        skipping = int(self.space_skipping and not self.contour)      # OptixRenderer.cpp:418-432
+        P = po.Params(self.dt, self.nprim, self.colormap_channel, self.grad, self.grad_iso, self.nprim, skipping)
         return fs, P
 
     def run_oracle(self, nthreads=8, frames=1, window=None):
@@ -106,6 +108,11 @@ class Case:
         for i, spec in enumerate(self.iso or []):
             iso_v[i], iso_c[i], iso_e[i] = spec[0], spec[1], 1
         R.updateIsoValues(iso_v, iso_c, iso_e)
+        if self.contour:
+            n = [c[0] for c in self.contour] + [[1, 0, 0]] * (3 - len(self.contour))
+            R.updateContourPlanes(n, [c[1] for c in self.contour] + [0.5] * (3 - len(self.contour)),
+                                  [c[2] for c in self.contour] + [0] * (3 - len(self.contour)),
+                                  [1] * len(self.contour) + [0] * (3 - len(self.contour)))
         R.setSpaceSkipping(bool(self.space_skipping))
         R.setGradientShadingDVR(bool(self.grad))
         R.setGradientShadingISO(bool(self.grad_iso))

@@ -33,6 +33,7 @@ GOLDEN_CASES = {
     "ex4_dvr_band": ("ex4", dict(W=64, H=48, xf="band")),
     "ex4_grad_iso2": ("ex4", dict(W=64, H=48, grad=1, iso=[(0.3, 0), (0.7, 0)])),
     "ex4_accum3": ("ex4", dict(W=64, H=48, grad=1, frames=3)),
+    "ex3_contour_iso": ("ex3", dict(W=64, H=48, grad=1, iso=[(0.6, 0)], contour=[([1, 1, 0.2], 0.55, 0)], opacity_scale=0.2)),
 }
 
 

@@ -55,6 +55,11 @@ CASES = {
     "amr_xfm_iso_ao": lambda: Case(_amr(), W=64, H=64, grad=0, iso=[(0.45, 0)], ao=1, ao_length=0.2,
                                    xfm=dict(vx=[24, 0, 0], vy=[0, 24, 0], vz=[0, 0, 16], p=[1, 2, 3]),
                                    camera=([-0.3, 2.6, 3.4], [0.9, 0.9, 0.8], [0, 1, 0], 60.0)),
+    "amr_contour": lambda: Case(_amr(), W=96, H=96, grad=1, opacity_scale=0.05,
+                                contour=[([1, 0.3, 0.2], 0.45, 0), ([0, 1, 0], 0.3, 0)]),
+    "amr_contour_iso": lambda: Case(_amr(), W=96, H=96, grad=0, opacity_scale=0.05, iso=[(0.45, 0)],
+                                    contour=[([0.2, 0.1, 1], 0.5, 0), ([1, 0, 0], 0.7, 0), ([0, 1, 0.5], 0.4, 0)]),
+    "ex3_contour": lambda: Case(scenes.example("ex3"), W=96, H=64, contour=[([1, 1, 0], 0.6, 0)]),
     "amr_inside": lambda: Case(_amr(), W=96, H=96, grad=1, camera=([20.3, 22.1, 14.2], [30, 20, 10], [0, 1, 0], 80.0)),
     "gen_exajet": lambda: Case(scenes.generated(kind="exajet", seed=11, root=(4, 2, 2), B=8, levels=3), W=160, H=96, grad=1),
 }

@@ -198,3 +198,24 @@ def test_trace_region_kd_equals_brute_force():
             d /= np.linalg.norm(d)
         r, t0, t1 = S.trace_region(active, o, d, 1e-6, 1e8)
         assert r != -2                           # kd-pruned search == brute force
+
+
+def test_contour_plane_colour_and_shading():
+    # constant field 0.5, fully transparent volume: the pixel is the plane's TF colour times |dot(dir, n)|
+    # (exabrick.cu:1396-1403, 1646-1648); the plane x = 0.5 of the unit cube maps to the middle of the bounds
+    sc = scenes.artificial(scenes.parse_grids("0 0 0 8 8 8 0  0.5"))
+    xf = np.zeros((128, 4), dtype=np.float32)
+    xf[:, 1] = np.arange(128) / 127.0           # g = value, alpha 0
+    case = Case(sc, W=16, H=16, xf=xf, xf_domains=[(0.0, 1.0)], contour=[([1, 0, 0], 0.5, 0)],
+                camera=([-10, 4.0, 4.0], [4, 4, 4], [0, 1, 0], 20.0))
+    rgba, acc, st = case.run_oracle(nthreads=1)
+    S = case.oracle_scene()
+    lo, hi = S.voxel_bounds()
+    cam = case.cam(lo, hi)
+    for (px, py) in [(8, 8), (3, 12)]:
+        rnd = po.lcg(px, py, 2)
+        d = cam["dir00"] + f32(px + rnd[0]) * cam["dirDu"] + f32(py + rnd[1]) * cam["dirDv"]
+        d = d / np.linalg.norm(d)
+        assert abs(float(acc[py, px, 1]) - 0.5 * abs(float(d[0]))) < 2e-3
+        assert acc[py, px, 0] == 0 and acc[py, px, 2] == 0
+    assert st["segments"] > 0                    # contour planes switch space skipping off: the volume is still walked
