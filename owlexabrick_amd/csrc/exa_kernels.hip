@@ -54,6 +54,11 @@ struct Lcg {
   }
 };
 
+// FAST (fast_math=1): 1-ulp hardware reciprocal / square root in the per-sample epilogue instead of the
+// correctly rounded expansions (~10 instructions each); the walk and the sample positions stay exact
+template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+template <bool FAST> __device__ __forceinline__ float fsqrt(float a) { return FAST ? __builtin_amdgcn_sqrtf(a) : sqrtf(a); }
+
 struct Ray { V3 org, dir; float tmin, tmax; };
 struct Color4 { float x, y, z, w; };
 
@@ -94,12 +99,13 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b)
 // (128 texels, linear, clamp, normalized coords) is a software lerp on the
 // LDS-resident table: x = u*128-0.5, T[i]*(1-a) + T[i+1]*a.
 // ------------------------------------------------------------------------
+template <bool FAST = false>
 __device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameState &fs, float in_scalar, int channel)
 {
   const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
-  float scalar = (EXA_NUM_XF_VALUES - 1) * (in_scalar - lo) / ((hi - lo) + 1e-20f);
+  float scalar = fdiv<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
   scalar = fminf(EXA_NUM_XF_VALUES - 1.f, fmaxf(0.f, scalar + .5f));
-  scalar /= EXA_NUM_XF_VALUES - 1.f;
+  scalar = fdiv<FAST>(scalar, EXA_NUM_XF_VALUES - 1.f);
   const float x = scalar * float(EXA_NUM_XF_VALUES) - 0.5f;
   const float fl = floorf(x);
   const float al = x - fl;
@@ -358,10 +364,10 @@ __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, C
                                                 float cellValue, V3 gradient, int finestLevelCellWidth, int channel)
 {
   if (actual_dt == 0.f) return;
-  Color4 sample = lookupXF(C.xfLds, C.a->fs, cellValue, channel);
-  if (length(gradient) > finestLevelCellWidth * 1e-6f) {
+  Color4 sample = lookupXF<FAST>(C.xfLds, C.a->fs, cellValue, channel);
+  if (fsqrt<FAST>(dot(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
-    const float scale = fabsf(dot(lightDir, gradient)) / sqrtf(dot(gradient, gradient) * dot(lightDir, lightDir));
+    const float scale = fdiv<FAST>(fabsf(dot(lightDir, gradient)), fsqrt<FAST>(dot(gradient, gradient) * dot(lightDir, lightDir)));
     sample.x *= scale; sample.y *= scale; sample.z *= scale;
   }
   // opacity correction 1-(1-a)^dt (exabrick.cu:1011).  FAST: pow as exp2(dt*log2(x)) on the
@@ -1282,7 +1288,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
       C.phase(ST_W_FINAL);
       if (B.sumW > 1e-20f) {
         C.count(ST_SAMPLES);
-        const float cellValue = B.sumWV / B.sumW;
+        const float cellValue = fdiv<FAST>(B.sumWV, B.sumW);
         V3 grad = mk(0.f, 0.f, 0.f);
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
