@@ -94,8 +94,13 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
-            raise RuntimeError(f"{LIB_PATH} not found: build it with __graft_entry__.build() "
-                               "(make -C owlexabrick_amd/csrc); there is no CPU fallback")
+            # not built yet: try to build the HIP module (hipcc cross-compiles without a GPU); never a CPU fallback
+            import subprocess
+            try:
+                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+            except Exception as e:  # noqa: BLE001
+                raise RuntimeError(f"{LIB_PATH} not found and building it failed ({e}); run "
+                                   "__graft_entry__.build(); there is no CPU fallback") from e
         L = C.CDLL(LIB_PATH)
         vp = C.c_void_p
         L.exa_prep_create.restype = C.c_int

@@ -1026,9 +1026,15 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
   }
   for (int seg = 0;; seg++) {
     if (seg >= (1 << 22)) { C.guardTripped = true; break; }
-    for (int g = 0; w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE; g++) {
-      if (g >= (1 << 24)) { C.guardTripped = true; w.ref = EXA_KD_DONE; break; }
-      kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale);
+    // wave-wide refill burst, as in the DVR loop: when one lane has run dry every lane still in this
+    // loop advances its own walk while it has a free queue slot
+    if (__any(w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
+      for (int g = 0;; g++) {
+        if (g >= (1 << 24)) { C.guardTripped = true; w.ref = EXA_KD_DONE; break; }
+        const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
+        if (!__any(want)) break;
+        if (want) kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale);
+      }
     }
     const int qc = w.pk.get(PK_QCOUNT);
     if (qc == 0) break;
