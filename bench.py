@@ -146,8 +146,9 @@ def main():
     stride = ((tiles + world - 1) // world) * 256 if world > 1 else W * H
     shard = torch.zeros(stride, dtype=torch.int32, device=dev)
     final = torch.zeros(W * H, dtype=torch.int32, device=dev) if (world > 1 and rank == 0) else None
-    gathered = [torch.zeros(stride, dtype=torch.int32, device=dev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # rank 0 receives every shard straight into its slice of one flat buffer (no concatenation step)
     gathered_flat = torch.zeros(stride * world, dtype=torch.int32, device=dev) if (world > 1 and rank == 0) else None
+    gathered = list(gathered_flat.chunk(world)) if gathered_flat is not None else None
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
@@ -157,8 +158,6 @@ def main():
         R.render(device_ptr=shard.data_ptr(), stream=stream)
         if backend == "nccl":
             dist.gather(shard, gathered, dst=0)
-            if rank == 0:
-                torch.cat(gathered, out=gathered_flat)
         else:
             host = shard.cpu()
             hl = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
