@@ -149,6 +149,7 @@ def main():
     # rank 0 receives every shard straight into its slice of one flat buffer (no concatenation step)
     gathered_flat = torch.zeros(stride * world, dtype=torch.int32, device=dev) if (world > 1 and rank == 0) else None
     gathered = list(gathered_flat.chunk(world)) if gathered_flat is not None else None
+    mode = {"collective": "gather"}
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
@@ -157,7 +158,15 @@ def main():
             return
         R.render(device_ptr=shard.data_ptr(), stream=stream)
         if backend == "nccl":
-            dist.gather(shard, gathered, dst=0)
+            if mode["collective"] == "gather":
+                try:
+                    dist.gather(shard, gathered, dst=0)       # each peer -> root over its own xGMI link
+                except RuntimeError as e:                     # defensive: fall back to an all-gather
+                    log(f"dist.gather failed ({e}); using all_gather_into_tensor")
+                    mode["collective"] = "all_gather"
+                    mode["flat"] = gathered_flat if rank == 0 else torch.zeros(stride * world, dtype=torch.int32, device=dev)
+            if mode["collective"] == "all_gather":
+                dist.all_gather_into_tensor(mode["flat"], shard)
         else:
             host = shard.cpu()
             hl = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
