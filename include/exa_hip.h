@@ -175,6 +175,12 @@ int exa_hip_set_frame_state(ExaHipRenderer *, const ExaHipFrameState *);
  * 128 x (r,g,b,a) for channel `chan`; marks the volume LBVH dirty. */
 int exa_hip_set_xf(ExaHipRenderer *, int32_t chan, const float *rgba128);
 
+/* the triangle surfaces of the OptixRenderer constructor (createSurfaces, exa/OptixRenderer.cpp:554-612;
+ * closest-hit shading programs/exabrick.cu:420-433): all meshes concatenated, world space,
+ * vertices 3 floats each, triangles 3 vertex indices each.  numTris = 0 removes them. */
+int exa_hip_set_triangles(ExaHipRenderer *, const float *vertices, uint64_t numVertices,
+                          const int32_t *triangles, uint64_t numTris);
+
 /* updateDt / setSpaceSkipping / setGradientShading* (exa/OptixRenderer.cpp:413-442) */
 int exa_hip_set_params(ExaHipRenderer *, const ExaHipParams *);
 

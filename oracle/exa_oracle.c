@@ -101,6 +101,7 @@ struct OrScene {
   int32_t  *leafList; size_t numLeaf, capLeaf;
   KdNode   *nodes; size_t numNodes, capNodes;
   float     xf[OR_MAX_CHANNELS][OR_NUM_XF_VALUES][4];
+  float    *meshVerts; int32_t *meshTris; size_t numVerts, numTris;   /* all surfaces, concatenated */
   float     vb_lo[3], vb_hi[3];
 };
 
@@ -344,6 +345,7 @@ void or_scene_destroy(OrScene *S)
   if (!S) return;
   free(S->bricks); free(S->scalars); free(S->offsets);
   free(S->regions); free(S->leafList); free(S->nodes);
+  free(S->meshVerts); free(S->meshTris);
   free(S);
 }
 
@@ -357,6 +359,17 @@ const int32_t *or_leaflist(const OrScene *S) { return S->leafList; }
 const float *or_scalars(const OrScene *S) { return S->scalars; }
 void or_voxel_bounds(const OrScene *S, float lo[3], float hi[3])
 { for (int k = 0; k < 3; k++) { lo[k] = S->vb_lo[k]; hi[k] = S->vb_hi[k]; } }
+
+/* the triangle meshes handed to the OptixRenderer constructor (OptixRenderer.cpp:554-612), world space */
+void or_set_triangles(OrScene *S, const float *verts, size_t numVerts, const int32_t *tris, size_t numTris)
+{
+  free(S->meshVerts); free(S->meshTris);
+  S->meshVerts = (float *)xmalloc(numVerts * 3 * sizeof(float));
+  S->meshTris = (int32_t *)xmalloc(numTris * 3 * sizeof(int32_t));
+  memcpy(S->meshVerts, verts, numVerts * 3 * sizeof(float));
+  memcpy(S->meshTris, tris, numTris * 3 * sizeof(int32_t));
+  S->numVerts = numVerts; S->numTris = numTris;
+}
 
 void or_set_xf(OrScene *S, int chan, const float *rgba128)
 { memcpy(S->xf[chan], rgba128, sizeof(S->xf[chan])); }
@@ -1015,10 +1028,37 @@ static SurfacePRD trace_contour_ray(Ctx *C, Ray ray, v3 normal, float offset, in
 
 /* exabrick.cu:1475-1529 traceSurfaces: contour planes and implicit iso-surfaces (meshes and
  * streamlines are SURVEY 8f rank 4) */
+/* The triangle trace of traceSurfaces (:1483-1486) and its closest-hit program (:420-433).  OptiX's
+ * built-in triangle intersector is not observable; the oracle uses the reference's own
+ * intersectRayTriangle (:1316-1343, Moeller-Trumbore) with t in (tmin,tmax), closest t, lowest
+ * triangle index on a tie.  Brute force over all triangles. */
+static void trace_meshes(Ctx *C, const Ray *ray, SurfacePRD *prd)
+{
+  const OrScene *S = C->S;
+  float best = ray->tmax;
+  long hit = -1;
+  for (size_t i = 0; i < S->numTris; i++) {
+    const int32_t *t = &S->meshTris[3 * i];
+    const v3 A = vfrom(&S->meshVerts[3 * t[0]]), B = vfrom(&S->meshVerts[3 * t[1]]), Cc = vfrom(&S->meshVerts[3 * t[2]]);
+    const float tt = intersect_ray_triangle(ray, A, vsub(B, A), vsub(Cc, A));
+    if (tt > ray->tmin && tt < best) { best = tt; hit = (long)i; }
+  }
+  if (hit >= 0) {
+    const int32_t *t = &S->meshTris[3 * hit];
+    const v3 A = vfrom(&S->meshVerts[3 * t[0]]), B = vfrom(&S->meshVerts[3 * t[1]]), Cc = vfrom(&S->meshVerts[3 * t[2]]);
+    prd->t_hit = best;
+    prd->primID = (int)hit;
+    prd->Ng = vnormalize(vcross(vsub(B, A), vsub(Cc, A)));
+    prd->ambient = .2f;
+    prd->baseColor = v3s(.8f);
+  }
+}
+
 static void trace_surfaces(Ctx *C, Ray ray, SurfacePRD *prd, int withContourPlanes)
 {
   prd->primID = -1;
   prd->t_hit = ray.tmax;
+  if (C->S->numTris) trace_meshes(C, &ray, prd);                 /* ST_MESHES, also for AO rays */
   if (withContourPlanes) {
     for (int i = 0; i < OR_MAX_CONTOUR_PLANES; ++i) {
       if (C->fs->contour[i].enabled) {

@@ -91,6 +91,7 @@ def lib():
             getattr(L, n).argtypes = [vp]
         L.or_voxel_bounds.argtypes = [vp, fp, fp]
         L.or_set_xf.argtypes = [vp, C.c_int, vp]
+        L.or_set_triangles.argtypes = [vp, vp, sz, vp, sz]
         L.or_volume_active.argtypes = [vp, C.POINTER(FrameState), C.POINTER(Params), vp]
         L.or_iso_active.argtypes = [vp, C.POINTER(FrameState), vp]
         L.or_render.argtypes = [vp, C.POINTER(FrameState), C.POINTER(Params)] + [C.c_int] * 6 + [vp, vp, C.POINTER(Stats), C.c_int]
@@ -180,6 +181,11 @@ class OracleScene:
     def set_xf(self, chan, rgba128):
         a = np.ascontiguousarray(rgba128, dtype=np.float32).reshape(128, 4)
         lib().or_set_xf(self.h, chan, a.ctypes.data)
+
+    def set_triangles(self, verts, tris):
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        lib().or_set_triangles(self.h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0])
 
     def volume_active(self, fs, params):
         out = np.zeros(self.num_regions, dtype=np.uint8)

@@ -81,7 +81,7 @@ KD_EMPTY = -2 ** 31
 # every symbol include/exa_hip.h declares
 ABI_SYMBOLS = ["exa_prep_create", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error",
                "exa_hip_create", "exa_hip_destroy", "exa_hip_resize", "exa_hip_set_frame_state",
-               "exa_hip_set_xf", "exa_hip_set_params", "exa_hip_set_shard", "exa_hip_output_pixels",
+               "exa_hip_set_xf", "exa_hip_set_triangles", "exa_hip_set_params", "exa_hip_set_shard", "exa_hip_output_pixels",
                "exa_hip_untile", "exa_hip_render", "exa_hip_render_stats", "exa_hip_get_stats",
                "exa_hip_read_accum", "exa_hip_write_accum", "exa_hip_read_activity",
                "exa_hip_set_option", "exa_hip_last_error"]
@@ -115,6 +115,7 @@ def lib():
         L.exa_hip_set_frame_state.argtypes = [vp, C.POINTER(ExaHipFrameState)]
         L.exa_hip_set_xf.argtypes = [vp, C.c_int32, vp]
         L.exa_hip_set_params.argtypes = [vp, C.POINTER(ExaHipParams)]
+        L.exa_hip_set_triangles.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
         L.exa_hip_set_shard.argtypes = [vp, C.c_int32, C.c_int32]
         L.exa_hip_output_pixels.restype = C.c_uint64
         L.exa_hip_output_pixels.argtypes = [vp]
@@ -236,6 +237,12 @@ class Renderer:
             self.frameState.iso[i].value = float(isoValues[i])
             self.frameState.iso[i].channel = int(channels[i])
             self.frameState.iso[i].enabled = int(enabled[i])
+
+    def setTriangles(self, verts, tris):
+        """the `surfaces` argument of the OptixRenderer constructor, all meshes concatenated"""
+        v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        self._check(lib().exa_hip_set_triangles(self.h, v.ctypes.data, v.shape[0], t.ctypes.data, t.shape[0]))
 
     def updateContourPlanes(self, normals, offsets, channels, enabled):
         for i in range(MAX_CONTOUR):

@@ -77,6 +77,10 @@ struct RenderArgs {
   const RegionRec   *regionRec;
   int32_t            kdRoot;
   float              kdLo[3], kdHi[3];   // box of the kd root = union of all brick domains
+  const BvhNode     *meshNodes;     // BVH over the triangle surfaces (NULL: none)
+  const float       *meshVerts;     // 3 floats per vertex, world space
+  const int32_t     *meshTris;      // 3 indices per triangle
+  int32_t            numTris;
   float              worldLo[3], worldHi[3];   // worldSpaceBounds (OptixRenderer.cpp:330-332), contour planes
   ExaHipFrameState   fs;
   ExaHipParams       p;

@@ -579,6 +579,58 @@ __device__ SurfaceHit traceContourRay(Ctx<STATS> &C, const Ray &ray, V3 normal, 
   return prd;
 }
 
+// ------------------------------------------------------------------------
+// triangle surfaces: the surfaceModel trace of traceSurfaces (exabrick.cu:1483-1486) and its
+// closest-hit program (:420-433).  OptiX's built-in triangle test is replaced by the reference's own
+// intersectRayTriangle (:1316-1343); closest t in (tmin,tmax), lowest triangle index on a tie.
+// ------------------------------------------------------------------------
+template <bool STATS>
+__device__ void traceMeshes(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
+{
+  const RenderArgs &a = *C.a;
+  float best = ray.tmax;
+  int hit = -1;
+  int stack[kStackDepth];
+  int sp = 0, node = 0;
+  Ray r = ray;
+  for (;;) {
+    const float4 *np = reinterpret_cast<const float4 *>(a.meshNodes + node);
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    const int4 cc = *reinterpret_cast<const int4 *>(np + 3);
+    r.tmax = best;
+    float a0, a1, b0, b1;
+    boxTest(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), a0, a1);
+    boxTest(r, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), b0, b1);
+    bool ha = a0 <= a1 && q0.x <= q0.w, hb = b0 <= b1 && q1.z <= q2.y;
+    for (int side = 0; side < 2; side++) {
+      const int c = side ? cc.y : cc.x;
+      if (!(side ? hb : ha) || c >= 0 || c == INT32_MIN) continue;
+      const int tri = ~c;
+      const int i0 = a.meshTris[3 * tri], i1 = a.meshTris[3 * tri + 1], i2 = a.meshTris[3 * tri + 2];
+      const V3 A = mk(a.meshVerts + 3 * i0), B = mk(a.meshVerts + 3 * i1), Cv = mk(a.meshVerts + 3 * i2);
+      const float tt = intersectRayTriangle(ray, A, B - A, Cv - A);
+      if (tt > ray.tmin && (tt < best || (tt == best && hit >= 0 && tri < hit))) { best = tt; hit = tri; }
+    }
+    ha = ha && cc.x >= 0; hb = hb && cc.y >= 0;
+    if (ha && hb) {
+      const bool aFirst = a0 <= b0;
+      if (sp < kStackDepth) stack[sp++] = aFirst ? cc.y : cc.x;
+      node = aFirst ? cc.x : cc.y;
+    } else if (ha) node = cc.x;
+    else if (hb) node = cc.y;
+    else { if (sp == 0) break; node = stack[--sp]; }
+  }
+  if (hit >= 0) {
+    const int i0 = a.meshTris[3 * hit], i1 = a.meshTris[3 * hit + 1], i2 = a.meshTris[3 * hit + 2];
+    const V3 A = mk(a.meshVerts + 3 * i0), B = mk(a.meshVerts + 3 * i1), Cv = mk(a.meshVerts + 3 * i2);
+    prd.t_hit = best;
+    prd.primID = hit;
+    prd.Ng = normalize(cross(B - A, Cv - A));
+    prd.ambient = .2f;
+    prd.baseColor = mk(.8f, .8f, .8f);
+  }
+}
+
 // exabrick.cu:1187-1256 isoIntegrateBrick
 template <bool STATS>
 __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellValue, IsoResult &ir, float off,
@@ -657,6 +709,7 @@ __device__ __forceinline__ void traceSurfaces(Ctx<STATS> &C, const Ray &ray, Sur
   prd.primID = -1;
   prd.t_hit = ray.tmax;
   prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
+  if (C.a->numTris > 0) traceMeshes(C, ray, prd);                 // ST_MESHES (also for AO rays)
   if (withContourPlanes) {
     for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; ++i)
       if (C.a->fs.contour[i].enabled) {
@@ -1092,6 +1145,7 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
   prd.primID = -1;
   prd.t_hit = ray.tmax;
   prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
+  if (C.a->numTris > 0) traceMeshes(C, ray, prd);                 // ST_MESHES (also for AO rays)
   if (withContourPlanes) {
     for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; ++i)
       if (C.a->fs.contour[i].enabled) {

@@ -87,17 +87,26 @@ struct LbvhTopology {
 
   void build(const ExaBrickRegion *regions, size_t n)
   {
+    std::vector<float> boxes(6 * n);
+    for (size_t i = 0; i < n; i++)
+      for (int k = 0; k < 3; k++) { boxes[6 * i + k] = regions[i].domain_lo[k]; boxes[6 * i + 3 + k] = regions[i].domain_hi[k]; }
+    build(boxes.data(), n);
+  }
+
+  // boxes: 6 floats (lo, hi) per primitive
+  void build(const float *boxes, size_t n)
+  {
     float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
     for (size_t i = 0; i < n; i++)
       for (int k = 0; k < 3; k++) {
-        lo[k] = std::fmin(lo[k], regions[i].domain_lo[k]);
-        hi[k] = std::fmax(hi[k], regions[i].domain_hi[k]);
+        lo[k] = std::fmin(lo[k], boxes[6 * i + k]);
+        hi[k] = std::fmax(hi[k], boxes[6 * i + 3 + k]);
       }
     std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
     for (size_t i = 0; i < n; i++) {
       uint64_t code = 0;
       for (int k = 0; k < 3; k++) {
-        const double c = 0.5 * (double(regions[i].domain_lo[k]) + double(regions[i].domain_hi[k]));
+        const double c = 0.5 * (double(boxes[6 * i + k]) + double(boxes[6 * i + 3 + k]));
         const double ext = double(hi[k]) - double(lo[k]);
         double u = ext > 0 ? (c - lo[k]) / ext : 0.0;
         u = std::min(std::max(u, 0.0), 1.0);
@@ -169,6 +178,12 @@ struct ExaHipRenderer {
   int accel = 1;                     // 1 = kd walk when available, 0 = LBVH
   float kdLo[3], kdHi[3];
 
+  // triangle surfaces
+  DevBuf<BvhNode> meshNodes;
+  DevBuf<float> meshVerts;
+  DevBuf<int32_t> meshTris;
+  int numTris = 0;
+
   // LBVH
   DevBuf<BvhNode> volNodes, isoNodes;
   DevBuf<int32_t> levelIds;
@@ -212,7 +227,7 @@ struct ExaHipRenderer {
     for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; i++) if (fs.contour[i].enabled) return true;
     return false;
   }
-  bool surfacesEnabled() const { return isoEnabled() || contourEnabled(); }
+  bool surfacesEnabled() const { return isoEnabled() || contourEnabled() || numTris > 0; }
   float voxLo[3], voxHi[3];
   // worldSpaceBounds = rcp(voxelSpaceTransform) applied to the voxel bounds (OptixRenderer.cpp:330-332);
   // rcp(affine3f) = inverse of the linear part by adjoint/determinant, p' = -(L^-1 p)
@@ -374,6 +389,7 @@ struct ExaHipRenderer {
     a.kdRoot = kdRoot;
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
     worldBounds(a.worldLo, a.worldHi);
+    a.meshNodes = meshNodes.p; a.meshVerts = meshVerts.p; a.meshTris = meshTris.p; a.numTris = numTris;
     HIP_TRY(this, hipEventRecord(ev0, s));
     if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfacesEnabled(), stats, s));
     else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, surfacesEnabled(), stats, s));
@@ -598,6 +614,55 @@ int exa_hip_set_xf(ExaHipRenderer *h, int32_t chan, const float *rgba128)
   std::memcpy(h->xfHost[chan], rgba128, sizeof(h->xfHost[chan]));
   h->xfDirty = true;
   h->volDirty = true;                      // needVolumeBVHRebuild = true (OptixRenderer.cpp:403)
+  return 0;
+}
+
+int exa_hip_set_triangles(ExaHipRenderer *h, const float *vertices, uint64_t numVertices,
+                          const int32_t *triangles, uint64_t numTris)
+{
+  if (!h) return 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  h->numTris = 0;
+  h->meshNodes.release(); h->meshVerts.release(); h->meshTris.release();
+  if (numTris == 0) return 0;
+  if (!vertices || !triangles || numTris > 0x3fffffffull) { h->fail("exa_hip_set_triangles: bad arguments"); return 1; }
+  for (uint64_t i = 0; i < 3 * numTris; i++)
+    if (triangles[i] < 0 || uint64_t(triangles[i]) >= numVertices) { h->fail("broken triangle model"); return 1; }   // TriangleMesh.cpp:43-52
+  // boxes, slightly padded so that axis-aligned triangles keep a non-degenerate slab interval
+  std::vector<float> boxes(6 * numTris);
+  for (uint64_t t = 0; t < numTris; t++)
+    for (int k = 0; k < 3; k++) {
+      const float a = vertices[3 * triangles[3 * t] + k], b = vertices[3 * triangles[3 * t + 1] + k], c = vertices[3 * triangles[3 * t + 2] + k];
+      const float lo = std::fmin(a, std::fmin(b, c)), hi = std::fmax(a, std::fmax(b, c));
+      const float pad = 1e-5f * std::fmax(std::fmax(std::fabs(lo), std::fabs(hi)), hi - lo) + 1e-30f;
+      boxes[6 * t + k] = lo - pad; boxes[6 * t + 3 + k] = hi + pad;
+    }
+  LbvhTopology topo;
+  topo.build(boxes.data(), numTris);
+  const size_t ni = topo.child0.size();
+  std::vector<BvhNode> nodes(ni);
+  std::vector<float> nlo(3 * ni), nhi(3 * ni);
+  auto childBox = [&](int32_t c, float *lo, float *hi) {
+    if (c == INT32_MIN) { for (int k = 0; k < 3; k++) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; } return; }
+    if (c < 0) { for (int k = 0; k < 3; k++) { lo[k] = boxes[6 * size_t(~c) + k]; hi[k] = boxes[6 * size_t(~c) + 3 + k]; } return; }
+    for (int k = 0; k < 3; k++) { lo[k] = nlo[3 * size_t(c) + k]; hi[k] = nhi[3 * size_t(c) + k]; }
+  };
+  for (size_t i = ni; i-- > 0;) {                       // children have larger indices than their parent
+    float l0[3], h0[3], l1[3], h1[3];
+    childBox(topo.child0[i], l0, h0);
+    childBox(topo.child1[i], l1, h1);
+    for (int k = 0; k < 3; k++) { nlo[3 * i + k] = std::fmin(l0[k], l1[k]); nhi[3 * i + k] = std::fmax(h0[k], h1[k]); }
+    BvhNode &n = nodes[i];
+    n.q0 = make_float4(l0[0], l0[1], l0[2], h0[0]);
+    n.q1 = make_float4(h0[1], h0[2], l1[0], l1[1]);
+    n.q2 = make_float4(l1[2], h1[0], h1[1], h1[2]);
+    n.child0 = topo.child0[i]; n.child1 = topo.child1[i]; n.pad0 = n.pad1 = 0;
+  }
+  HIP_TRY(h, h->meshNodes.upload(nodes.data(), nodes.size()));
+  HIP_TRY(h, h->meshVerts.upload(vertices, 3 * numVertices));
+  HIP_TRY(h, h->meshTris.upload(triangles, 3 * numTris));
+  h->numTris = (int)numTris;
   return 0;
 }
 

@@ -307,7 +307,7 @@ static void check(int rc, ExaHipRenderer *h)
   if (rc) throw std::runtime_error(exa_hip_last_error(h));
 }
 
-Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP>, std::vector<ScalarField::SP> fields, int device)
+Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP> surfaces, std::vector<ScalarField::SP> fields, int device)
   : scalarFields(fields), input(in)
 {
   if (!in || in->numBricks() == 0) throw std::runtime_error("no bricks");
@@ -326,6 +326,20 @@ Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP>, std::vector<
     const std::string msg = exa_hip_last_error(nullptr);
     exa_prep_destroy(prep);
     prep = nullptr;
+    throw std::runtime_error(msg);
+  }
+  // createSurfaces (OptixRenderer.cpp:554-612): all meshes go into one triangle set
+  std::vector<float> verts;
+  std::vector<int32_t> tris;
+  for (auto &m : surfaces) {
+    const int32_t base = (int32_t)(verts.size() / 3);
+    for (const vec3f &v : m->vertex) { verts.push_back(v.x); verts.push_back(v.y); verts.push_back(v.z); }
+    for (const vec3i &t : m->index) { tris.push_back(base + t.x); tris.push_back(base + t.y); tris.push_back(base + t.z); }
+  }
+  if (!tris.empty() && exa_hip_set_triangles(handle, verts.data(), verts.size() / 3, tris.data(), tris.size() / 3)) {
+    const std::string msg = exa_hip_last_error(handle);
+    exa_hip_destroy(handle); exa_prep_destroy(prep);
+    handle = nullptr; prep = nullptr;
     throw std::runtime_error(msg);
   }
   params.dt = 0.5f;

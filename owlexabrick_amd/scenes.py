@@ -304,7 +304,7 @@ def config(name, scale=1.0, threads=0, fill=True):
     return generated(kind=kind, root=root, threads=threads, fill=fill, name=name, **c)
 
 
-def write_exa(scene, directory, name="scene", remap=None):
+def write_exa(scene, directory, name="scene", remap=None, meshes=None):
     """write the scene in the reference's on-disk formats: `.bricks` (per brick int32
     size[3], lower[3], level, cellIDs[]; builder/builder.cpp:895-902), one raw-float32
     `.scalars` per field in cell-id order (exa/ScalarField.cpp:22-34) and the `.exa`
@@ -322,6 +322,14 @@ def write_exa(scene, directory, name="scene", remap=None):
     for i, fld in enumerate(scene.fields):
         np.asarray(fld, dtype=np.float32).tofile(os.path.join(directory, f"{name}_{i}.scalars"))
         lines.append(f"scalar field{i} {name}_{i}.scalars")
+    if meshes:
+        # triangle file: repeated int32 nVerts, vec3f[nVerts], int32 nTris, vec3i[nTris] (exa/TriangleMesh.cpp:21-53)
+        with open(os.path.join(directory, name + ".tris"), "wb") as f:
+            for verts, tris in meshes:
+                v = np.asarray(verts, dtype=np.float32).reshape(-1, 3)
+                t = np.asarray(tris, dtype=np.int32).reshape(-1, 3)
+                f.write(np.int32(len(v)).tobytes() + v.tobytes() + np.int32(len(t)).tobytes() + t.tobytes())
+        lines.append(f"triangles {name}.tris")
     if remap is not None:
         lines.append("remap_from " + " ".join(str(float(v)) for v in remap[0]))
         lines.append("remap_to " + " ".join(str(float(v)) for v in remap[1]))

@@ -30,7 +30,7 @@ def band_xf(lo=0.35, hi=0.65):
 class Case:
     def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
                  space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
-                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None, contour=None):
+                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None, contour=None, meshes=None):
         self.scene, self.W, self.H = scene, W, H
         self.grad, self.iso, self.dt = grad, iso, dt
         self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
@@ -40,6 +40,7 @@ class Case:
         self.accel = accel
         self.fast_math = fast_math
         self.contour = contour
+        self.meshes = meshes          # list of (verts[n,3], tris[m,3]), world space
         nf = len(scene.fields)
         self.nprim = nf if multi else 1
         self.colormap_channel = 0 if (multi or nf < 2) else 1
@@ -65,7 +66,18 @@ class Case:
                            num_region_fields=len(self.scene.fields) if self.multi else 1)
         for c, xf in enumerate(self.xfs):
             S.set_xf(c, xf)
+        if self.meshes:
+            S.set_triangles(*self._merged_meshes())
         return S
+
+    def _merged_meshes(self):
+        verts, tris, base = [], [], 0
+        for v, t in self.meshes:
+            v = np.asarray(v, dtype=np.float32).reshape(-1, 3)
+            verts.append(v)
+            tris.append(np.asarray(t, dtype=np.int32).reshape(-1, 3) + base)
+            base += len(v)
+        return np.concatenate(verts), np.concatenate(tris)
 
     def oracle_state(self, S, frameID=None):
         lo, hi = S.voxel_bounds()
@@ -92,6 +104,8 @@ class Case:
         from owlexabrick_amd import binding
         prep = binding.Prep(self.scene, num_region_fields=len(self.scene.fields) if self.multi else 1)
         R = binding.Renderer(prep, device=device, multiFieldDvr=self.multi)
+        if self.meshes:
+            R.setTriangles(*self._merged_meshes())
         if self.accel is not None:
             R.setOption("accel", self.accel)
         if self.fast_math is not None:

@@ -22,6 +22,15 @@ def _amr():
     return scenes.amr(seed=3, root=(3, 3, 2), B=4, levels=3)
 
 
+def _meshes():
+    """an octahedron inside the _amr() volume and an axis-aligned quad (degenerate box on one axis)"""
+    c, r = np.array([24.0, 22.0, 14.0]), 9.0
+    v = [c + r * np.array(d) for d in ([1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1])]
+    t = [[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]
+    quad_v = [[5, 5, 6], [40, 5, 6], [40, 40, 6], [5, 40, 6]]
+    return [(np.array(v), np.array(t)), (np.array(quad_v, dtype=np.float64), np.array([[0, 1, 2], [0, 2, 3]]))]
+
+
 CASES = {
     "ex0": lambda: Case(scenes.example("ex0"), W=96, H=64),
     "ex1_grad": lambda: Case(scenes.example("ex1"), W=96, H=64, grad=1),
@@ -60,6 +69,10 @@ CASES = {
     "amr_contour_iso": lambda: Case(_amr(), W=96, H=96, grad=0, opacity_scale=0.05, iso=[(0.45, 0)],
                                     contour=[([0.2, 0.1, 1], 0.5, 0), ([1, 0, 0], 0.7, 0), ([0, 1, 0.5], 0.4, 0)]),
     "ex3_contour": lambda: Case(scenes.example("ex3"), W=96, H=64, contour=[([1, 1, 0], 0.6, 0)]),
+    "amr_mesh": lambda: Case(_amr(), W=96, H=96, grad=1, opacity_scale=0.05, meshes=_meshes()),
+    "amr_mesh_iso_contour": lambda: Case(_amr(), W=96, H=96, grad=0, opacity_scale=0.05, meshes=_meshes(), iso=[(0.5, 0)],
+                                         contour=[([1, 0, 0.3], 0.6, 0)]),
+    "amr_mesh_ao": lambda: Case(_amr(), W=64, H=64, grad=1, opacity_scale=0.05, meshes=_meshes(), ao=1, ao_length=12.0),
     "amr_inside": lambda: Case(_amr(), W=96, H=96, grad=1, camera=([20.3, 22.1, 14.2], [30, 20, 10], [0, 1, 0], 80.0)),
     "gen_exajet": lambda: Case(scenes.generated(kind="exajet", seed=11, root=(4, 2, 2), B=8, levels=3), W=160, H=96, grad=1),
 }

@@ -56,7 +56,9 @@ def test_exarender_matches_binding_and_oracle():
     grey = np.repeat((np.arange(128, dtype=np.float32) / 127.0)[:, None], 4, axis=1)
     W, H = 80, 48
     with tempfile.TemporaryDirectory() as d:
-        cfg = scenes.write_exa(sc, d, "amr")
+        tri_v = np.array([[6, 6, 5], [28, 6, 5], [16, 28, 9]], dtype=np.float32)
+        tri_t = np.array([[0, 1, 2]], dtype=np.int32)
+        cfg = scenes.write_exa(sc, d, "amr", meshes=[(tri_v, tri_t)])
         out = os.path.join(d, "o.ppm")
         r = _run([cfg, "--size", str(W), str(H), "-o", out, "--frames", "1", "--isovals", "0.4", "0.4"])
         assert r.returncode == 0, r.stderr
@@ -68,7 +70,8 @@ def test_exarender_matches_binding_and_oracle():
         assert data.startswith(hdr)
         img = np.frombuffer(data[len(hdr):], dtype=np.uint8).reshape(H, W, 3)[::-1]
     dom = (float(min(sc.fields[0].min(), 0.0)), float(max(sc.fields[0].max(), 0.0)))
-    case = Case(sc, W=W, H=H, grad=1, xf=grey, xf_domains=[dom], iso=[(0.4, 0), (0.4, 0)], camera=cam)
+    case = Case(sc, W=W, H=H, grad=1, xf=grey, xf_domains=[dom], iso=[(0.4, 0), (0.4, 0)], camera=cam,
+                meshes=[(tri_v, tri_t)])
     h = case.run_hip()
     assert np.array_equal(harness.unpack_rgba8(h[0])[..., :3], img)      # facade == Python binding, same module
     o = case.run_oracle()
