@@ -181,6 +181,22 @@ int exa_hip_set_xf(ExaHipRenderer *, int32_t chan, const float *rgba128);
 int exa_hip_set_triangles(ExaHipRenderer *, const float *vertices, uint64_t numVertices,
                           const int32_t *triangles, uint64_t numTris);
 
+/* streamline tracer (OptixRenderer::traces, exa/OptixRenderer.h:160-170) */
+typedef struct ExaHipTracer {
+  int32_t enabled;          /* setTracerEnabled                                   */
+  int32_t channels[3];      /* the three scalar fields read as a velocity          */
+  int32_t numTraces, numTimesteps;
+  float   steplen;
+} ExaHipTracer;
+/* resetTracer (exa/OptixRenderer.cpp:450-472): seeds (numTraces x 3, the caller draws them) become
+ * timestep 0 of every trace, the rest is cleared, the current timestep returns to 0 */
+int exa_hip_reset_tracer(ExaHipRenderer *, const ExaHipTracer *, const float *seeds);
+int exa_hip_set_tracer_enabled(ExaHipRenderer *, int32_t enabled);
+/* advanceTracer (:474-487): next timestep; *rebuild = needStreamlineBVHRebuild */
+int exa_hip_advance_tracer(ExaHipRenderer *, int32_t *rebuild);
+/* numTraces * numTimesteps * 3 floats */
+int exa_hip_read_traces(ExaHipRenderer *, float *dst);
+
 /* updateDt / setSpaceSkipping / setGradientShading* (exa/OptixRenderer.cpp:413-442) */
 int exa_hip_set_params(ExaHipRenderer *, const ExaHipParams *);
 

@@ -102,6 +102,9 @@ struct OrScene {
   KdNode   *nodes; size_t numNodes, capNodes;
   float     xf[OR_MAX_CHANNELS][OR_NUM_XF_VALUES][4];
   float    *meshVerts; int32_t *meshTris; size_t numVerts, numTris;   /* all surfaces, concatenated */
+  /* streamline tracer state (OptixRenderer.h:160-170) */
+  int tracerEnabled, tracerChannels[3], numTraces, numTimesteps, timestep;
+  float steplen; float *traces;                                        /* numTraces*numTimesteps*3 */
   float     vb_lo[3], vb_hi[3];
 };
 
@@ -345,7 +348,7 @@ void or_scene_destroy(OrScene *S)
   if (!S) return;
   free(S->bricks); free(S->scalars); free(S->offsets);
   free(S->regions); free(S->leafList); free(S->nodes);
-  free(S->meshVerts); free(S->meshTris);
+  free(S->meshVerts); free(S->meshTris); free(S->traces);
   free(S);
 }
 
@@ -359,6 +362,28 @@ const int32_t *or_leaflist(const OrScene *S) { return S->leafList; }
 const float *or_scalars(const OrScene *S) { return S->scalars; }
 void or_voxel_bounds(const OrScene *S, float lo[3], float hi[3])
 { for (int k = 0; k < 3; k++) { lo[k] = S->vb_lo[k]; hi[k] = S->vb_hi[k]; } }
+
+/* OptixRenderer::resetTracer (OptixRenderer.cpp:450-472): seeds at timestep 0, everything else 0, timestep 0 */
+void or_reset_tracer(OrScene *S, int enabled, const int channels[3], int numTraces, int numTimesteps, float steplen,
+                     const float *seeds)
+{
+  free(S->traces);
+  S->tracerEnabled = enabled; S->numTraces = numTraces; S->numTimesteps = numTimesteps; S->steplen = steplen;
+  for (int k = 0; k < 3; k++) S->tracerChannels[k] = channels[k];
+  S->traces = (float *)calloc((size_t)numTraces * numTimesteps * 3 + 1, sizeof(float));
+  if (!S->traces) die_oom();
+  for (int i = 0; i < numTraces; i++) memcpy(&S->traces[(size_t)i * numTimesteps * 3], &seeds[3 * i], 3 * sizeof(float));
+  S->timestep = 0;
+}
+/* OptixRenderer::advanceTracer (:474-487) */
+int or_advance_tracer(OrScene *S)
+{
+  if (!S->tracerEnabled) return 0;
+  S->timestep++;
+  return S->timestep <= S->numTimesteps;
+}
+const float *or_traces(const OrScene *S) { return S->traces; }
+int or_tracer_timestep(const OrScene *S) { return S->timestep; }
 
 /* the triangle meshes handed to the OptixRenderer constructor (OptixRenderer.cpp:554-612), world space */
 void or_set_triangles(OrScene *S, const float *verts, size_t numVerts, const int32_t *tris, size_t numTris)
@@ -1028,6 +1053,121 @@ static SurfacePRD trace_contour_ray(Ctx *C, Ray ray, v3 normal, float offset, in
 
 /* exabrick.cu:1475-1529 traceSurfaces: contour planes and implicit iso-surfaces (meshes and
  * streamlines are SURVEY 8f rank 4) */
+/* ------------------------------------------------------------------ */
+/* streamlines                                      */
+/* ------------------------------------------------------------------ */
+#define PRIMID_STREAMLINE (-25)
+
+/* exabrick.cu:440-502 intersectRoundedCone */
+static int intersect_rounded_cone(v3 pa, v3 pb, float ra, float rb, const Ray *ray, float *hit_t, v3 *isec_normal)
+{
+  v3 ro = ray->org;
+  const v3 rd = ray->dir;
+  float minDist = fmaxf(0.f, fminf(vlength(vsub(pa, ro)) - ra, vlength(vsub(pb, ro)) - rb));
+  ro = vadd(ro, vscale(minDist, rd));
+  v3 ba = vsub(pb, pa), oa = vsub(ro, pa), ob = vsub(ro, pb);
+  float rr = ra - rb;
+  float m0 = vdot(ba, ba), m1 = vdot(ba, oa), m2 = vdot(ba, rd), m3 = vdot(rd, oa), m5 = vdot(oa, oa);
+  float m6 = vdot(ob, rd), m7 = vdot(ob, ob);
+  (void)m6; (void)m7;
+  float d2 = m0 - rr * rr;
+  float k2 = d2 - m2 * m2;
+  float k1 = d2 * m3 - m1 * m2 + m2 * rr * ra;
+  float k0 = d2 * m5 - m1 * m1 + m1 * rr * ra * 2.0f - m0 * ra * ra;
+  float h = k1 * k1 - k0 * k2;
+  if (h < 0.0f) return 0;
+  float t = (-sqrtf(h) - k1) / k2;
+  float y = m1 - ra * rr + t * m2;
+  if (y > 0.0f && y < d2) {
+    *hit_t = minDist + t;
+    *isec_normal = vsub(vscale(d2, vadd(oa, vscale(t, rd))), vscale(y, ba));
+    return 1;
+  }
+  float h1 = m3 * m3 - m5 + ra * ra;                          /* caps */
+  if (h1 > 0.0f) {
+    t = -m3 - sqrtf(h1);
+    *hit_t = minDist + t;
+    *isec_normal = vdiv(vadd(oa, vscale(t, rd)), v3s(ra));
+    return 1;
+  }
+  return 0;
+}
+
+/* the streamlineBVH trace of traceSurfaces (:1503-1512) with the Streamline bounds/intersect programs
+ * (:504-570): segments hidden by the bounds program are skipped, closest accepted t in [tmin, best],
+ * lowest primitive id on a tie.  Brute force. */
+static void trace_streamlines(Ctx *C, const Ray *ray, SurfacePRD *prd)
+{
+  const OrScene *S = C->S;
+  if (!S->traces) return;
+  const int NT = S->numTimesteps, t = S->timestep;
+  const long nprims = (long)S->numTraces * (NT - 1);
+  float best = 2e10f;                                           /* streamlinePRD.t_hit = 2e10f (:1507) */
+  long hit = -1;
+  v3 bestN = v3s(0.f);
+  Ray r = *ray;
+  for (long p = 0; p < nprims; p++) {
+    if ((int)(p % NT) >= t - 1) continue;                       /* :546-551 */
+    const v3 pa = vfrom(&S->traces[3 * p]), pb = vfrom(&S->traces[3 * (p + 1)]);
+    if (!(pa.x < 2e10f && pb.x < 2e10f)) continue;              /* :559-570 */
+    float th; v3 n;
+    if (!intersect_rounded_cone(pa, pb, 2.f, 2.f, &r, &th, &n)) continue;
+    if (th >= ray->tmin && th <= ray->tmax && th < best) { best = th; hit = p; bestN = n; }
+  }
+  if (hit >= 0 && best < prd->t_hit) {                          /* :1510-1511 */
+    prd->primID = PRIMID_STREAMLINE;
+    prd->t_hit = best;
+    prd->Ng = vnormalize(bestN);
+    prd->baseColor = v3s(.8f);
+    prd->ambient = 0.f;   /* never written by the reference for streamlines (uninitialised there) */
+  }
+}
+
+/* exabrick.cu:945-963 sampleDirection */
+static int sample_direction(Ctx *C, v3 pos, v3 *result)
+{
+  Ray ray = { pos, V3(1.f, 1.f, 1.f), 0.f, 2e-10f };
+  RegionHit prd = trace_region(C->S, C->volActive, &ray);
+  if (prd.leafID < 0) return 0;                                 /* reference: region[-1], undefined */
+  float r[3] = {0.f, 0.f, 0.f};
+  for (int i = 0; i < 3; ++i)
+    if (!sample_point(C, &r[i], prd.leafID, pos, C->S->tracerChannels[i])) { *result = V3(r[0], r[1], r[2]); return 0; }
+  *result = V3(r[0], r[1], r[2]);
+  return 1;
+}
+
+/* exabrick.cu:1531-1574 computeTraces for trace i (the thread with pixelIdx == i) */
+static void compute_trace(Ctx *C, int i)
+{
+  OrScene *S = (OrScene *)C->S;
+  const int t = S->timestep, NT = S->numTimesteps;
+  if (!(t >= 1 && t < NT && i < S->numTraces && S->traces)) return;   /* t == 0 would read traces[-1] (undefined in the reference) */
+  v3 wlo, whi;
+  world_space_bounds(S, C->fs, &wlo, &whi);
+  v3 p = vfrom(&S->traces[3 * ((size_t)i * NT + (t - 1))]);
+  const v3 pp = p;
+  if (p.x < 2e10f) {
+    int valid = 1;
+    v3 k1 = v3s(0.f), k2 = v3s(0.f), k3 = v3s(0.f), k4 = v3s(0.f);
+    valid &= sample_direction(C, p, &k1);
+    k1 = vscale(S->steplen, k1);
+    v3 ptry1 = vadd(p, vscale(.5f, k1));
+    valid &= sample_direction(C, ptry1, &k2);
+    k2 = vscale(S->steplen, k2);
+    v3 ptry2 = vadd(p, vscale(.5f, k2));
+    valid &= sample_direction(C, ptry2, &k3);
+    k3 = vscale(S->steplen, k3);
+    v3 ptry3 = vadd(p, k3);
+    valid &= sample_direction(C, ptry3, &k4);
+    k4 = vscale(S->steplen, k4);
+    p = vadd(p, vscale(1 / 6.f, vadd(vadd(vadd(k1, vscale(2.f, k2)), vscale(2.f, k3)), k4)));
+    const int inside = p.x >= wlo.x && p.y >= wlo.y && p.z >= wlo.z && p.x <= whi.x && p.y <= whi.y && p.z <= whi.z;
+    if (!valid || !inside || vlength(vsub(p, pp)) < 1e-10f) p = v3s(2e10f);
+  }
+  float *dst = &S->traces[3 * ((size_t)i * NT + t)];
+  dst[0] = p.x; dst[1] = p.y; dst[2] = p.z;
+}
+
 /* The triangle trace of traceSurfaces (:1483-1486) and its closest-hit program (:420-433).  OptiX's
  * built-in triangle intersector is not observable; the oracle uses the reference's own
  * intersectRayTriangle (:1316-1343, Moeller-Trumbore) with t in (tmin,tmax), closest t, lowest
@@ -1068,6 +1208,7 @@ static void trace_surfaces(Ctx *C, Ray ray, SurfacePRD *prd, int withContourPlan
       }
     }
   }
+  trace_streamlines(C, &ray, prd);                              /* ST_STREAMLINES :1503-1512 */
   int activeIsoSurfaces = 0;
   for (int i = 0; i < OR_MAX_ISO_SURFACES; i++) activeIsoSurfaces |= C->fs->iso[i].enabled;
   if (activeIsoSurfaces) {
@@ -1109,8 +1250,9 @@ static void render_pixel(Ctx *C, int px, int py, int W, int H, uint32_t *rgba, f
   trace_surfaces(C, ray, &surface, 1);                                       /* :1601 ST_ALL_SURFACES */
 
   v3 bgColor = v3s(0.f);
-  if (surface.primID >= 0 || surface.primID == PRIMID_ISOSURFACE || surface.primID == PRIMID_PLANE) { /* :1604 */
-    const int shade = surface.primID >= 0 || surface.primID == PRIMID_PLANE
+  if (surface.primID >= 0 || surface.primID == PRIMID_ISOSURFACE || surface.primID == PRIMID_PLANE
+      || surface.primID == PRIMID_STREAMLINE) {                                   /* :1604 */
+    const int shade = surface.primID >= 0 || surface.primID == PRIMID_PLANE || surface.primID == PRIMID_STREAMLINE
                    || (surface.primID == PRIMID_ISOSURFACE && C->P->gradientShadingISO);
     if (shade && vlength(surface.Ng) > 0.f) {
       const float AO_Radius = fs->ao.length;
@@ -1126,7 +1268,8 @@ static void render_pixel(Ctx *C, int px, int py, int W, int H, uint32_t *rgba, f
         Ray ao_ray = {isect_pos, dir, 1e-4f, AO_Radius};
         SurfacePRD ao;
         trace_surfaces(C, ao_ray, &ao, 0);                                   /* :1637-1639 no contour planes */
-        if (ao.primID >= 0 || ao.primID == PRIMID_ISOSURFACE || ao.primID == PRIMID_PLANE) hitCnt++;
+        if (ao.primID >= 0 || ao.primID == PRIMID_ISOSURFACE || ao.primID == PRIMID_PLANE
+            || ao.primID == PRIMID_STREAMLINE) hitCnt++;
       }
       float shadow = fs->ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
       /* :1646-1648  ambient + baseColor*fabs(dot(dir,Ng))*(1-shadow), left to right */
@@ -1229,6 +1372,11 @@ void or_render(const OrScene *S, const OrFrameState *fs, const OrParams *P,
   uint8_t *volActive = (uint8_t *)xmalloc(S->numRegions), *isoActive = (uint8_t *)xmalloc(S->numRegions);
   or_volume_active(S, fs, P, volActive);
   or_iso_active(S, fs, isoActive);
+  if (S->tracerEnabled && S->traces) {          /* renderFrame :1581-1582; trace i is advanced by the thread of pixel i */
+    Ctx tc; memset(&tc, 0, sizeof(tc));
+    tc.S = S; tc.fs = fs; tc.P = P; tc.volActive = volActive; tc.isoActive = isoActive;
+    for (int i = 0; i < S->numTraces && i < W * H; i++) compute_trace(&tc, i);
+  }
   pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
   volatile int nextRow = 0;
   Job *jobs = (Job *)xmalloc((size_t)nthreads * sizeof(Job));

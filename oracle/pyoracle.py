@@ -92,6 +92,13 @@ def lib():
         L.or_voxel_bounds.argtypes = [vp, fp, fp]
         L.or_set_xf.argtypes = [vp, C.c_int, vp]
         L.or_set_triangles.argtypes = [vp, vp, sz, vp, sz]
+        L.or_reset_tracer.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, vp]
+        L.or_advance_tracer.restype = C.c_int
+        L.or_advance_tracer.argtypes = [vp]
+        L.or_traces.restype = vp
+        L.or_traces.argtypes = [vp]
+        L.or_tracer_timestep.restype = C.c_int
+        L.or_tracer_timestep.argtypes = [vp]
         L.or_volume_active.argtypes = [vp, C.POINTER(FrameState), C.POINTER(Params), vp]
         L.or_iso_active.argtypes = [vp, C.POINTER(FrameState), vp]
         L.or_render.argtypes = [vp, C.POINTER(FrameState), C.POINTER(Params)] + [C.c_int] * 6 + [vp, vp, C.POINTER(Stats), C.c_int]
@@ -181,6 +188,19 @@ class OracleScene:
     def set_xf(self, chan, rgba128):
         a = np.ascontiguousarray(rgba128, dtype=np.float32).reshape(128, 4)
         lib().or_set_xf(self.h, chan, a.ctypes.data)
+
+    def reset_tracer(self, enabled, channels, num_traces, num_timesteps, steplen, seeds):
+        sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(num_traces, 3)
+        self._tracer = (num_traces, num_timesteps)
+        lib().or_reset_tracer(self.h, int(enabled), (C.c_int * 3)(*channels), num_traces, num_timesteps, steplen, sd.ctypes.data)
+
+    def advance_tracer(self):
+        return bool(lib().or_advance_tracer(self.h))
+
+    def traces(self):
+        n, nt = self._tracer
+        buf = (C.c_char * (n * nt * 12)).from_address(lib().or_traces(self.h))
+        return np.frombuffer(buf, dtype=np.float32).reshape(n, nt, 3).copy()
 
     def set_triangles(self, verts, tris):
         v = np.ascontiguousarray(verts, dtype=np.float32).reshape(-1, 3)

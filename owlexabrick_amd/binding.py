@@ -49,6 +49,11 @@ class ExaHipParams(C.Structure):
                 ("numChannels", C.c_int32), ("spaceSkippingEnabled", C.c_int32)]
 
 
+class ExaHipTracer(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("channels", C.c_int32 * 3), ("numTraces", C.c_int32),
+                ("numTimesteps", C.c_int32), ("steplen", C.c_float)]
+
+
 class ExaHipScene(C.Structure):
     _fields_ = [("bricks", C.c_void_p), ("numBricks", C.c_uint64),
                 ("regions", C.c_void_p), ("numRegions", C.c_uint64),
@@ -81,7 +86,8 @@ KD_EMPTY = -2 ** 31
 # every symbol include/exa_hip.h declares
 ABI_SYMBOLS = ["exa_prep_create", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error",
                "exa_hip_create", "exa_hip_destroy", "exa_hip_resize", "exa_hip_set_frame_state",
-               "exa_hip_set_xf", "exa_hip_set_triangles", "exa_hip_set_params", "exa_hip_set_shard", "exa_hip_output_pixels",
+               "exa_hip_set_xf", "exa_hip_set_triangles", "exa_hip_reset_tracer", "exa_hip_set_tracer_enabled",
+               "exa_hip_advance_tracer", "exa_hip_read_traces", "exa_hip_set_params", "exa_hip_set_shard", "exa_hip_output_pixels",
                "exa_hip_untile", "exa_hip_render", "exa_hip_render_stats", "exa_hip_get_stats",
                "exa_hip_read_accum", "exa_hip_write_accum", "exa_hip_read_activity",
                "exa_hip_set_option", "exa_hip_last_error"]
@@ -116,6 +122,10 @@ def lib():
         L.exa_hip_set_xf.argtypes = [vp, C.c_int32, vp]
         L.exa_hip_set_params.argtypes = [vp, C.POINTER(ExaHipParams)]
         L.exa_hip_set_triangles.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint64]
+        L.exa_hip_reset_tracer.argtypes = [vp, C.POINTER(ExaHipTracer), vp]
+        L.exa_hip_set_tracer_enabled.argtypes = [vp, C.c_int32]
+        L.exa_hip_advance_tracer.argtypes = [vp, C.POINTER(C.c_int32)]
+        L.exa_hip_read_traces.argtypes = [vp, vp]
         L.exa_hip_set_shard.argtypes = [vp, C.c_int32, C.c_int32]
         L.exa_hip_output_pixels.restype = C.c_uint64
         L.exa_hip_output_pixels.argtypes = [vp]
@@ -237,6 +247,25 @@ class Renderer:
             self.frameState.iso[i].value = float(isoValues[i])
             self.frameState.iso[i].channel = int(channels[i])
             self.frameState.iso[i].enabled = int(enabled[i])
+
+    # ---- streamline tracer (OptixRenderer::setTracerEnabled / resetTracer / advanceTracer) ----
+    def resetTracer(self, seeds, channels=(0, 1, 2), numTimesteps=100, steplen=1e-6, enabled=True):
+        sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(-1, 3)
+        self._tracer = ExaHipTracer(int(enabled), (C.c_int32 * 3)(*channels), sd.shape[0], int(numTimesteps), float(steplen))
+        self._check(lib().exa_hip_reset_tracer(self.h, C.byref(self._tracer), sd.ctypes.data))
+
+    def setTracerEnabled(self, enable):
+        self._check(lib().exa_hip_set_tracer_enabled(self.h, int(bool(enable))))
+
+    def advanceTracer(self):
+        r = C.c_int32(0)
+        self._check(lib().exa_hip_advance_tracer(self.h, C.byref(r)))
+        return bool(r.value)
+
+    def readTraces(self):
+        out = np.zeros((self._tracer.numTraces, self._tracer.numTimesteps, 3), dtype=np.float32)
+        self._check(lib().exa_hip_read_traces(self.h, out.ctypes.data))
+        return out
 
     def setTriangles(self, verts, tris):
         """the `surfaces` argument of the OptixRenderer constructor, all meshes concatenated"""

@@ -81,6 +81,11 @@ struct RenderArgs {
   const float       *meshVerts;     // 3 floats per vertex, world space
   const int32_t     *meshTris;      // 3 indices per triangle
   int32_t            numTris;
+  const BvhNode     *streamNodes;   // BVH over the visible streamline segments (NULL: none)
+  const float       *traces;        // numTraces x numTimesteps x 3
+  int32_t            numStreamPrims;
+  int32_t            tracerChannels[3], numTraces, numTimesteps, timestep;
+  float              steplen;
   float              worldLo[3], worldHi[3];   // worldSpaceBounds (OptixRenderer.cpp:330-332), contour planes
   ExaHipFrameState   fs;
   ExaHipParams       p;
@@ -107,6 +112,8 @@ hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const 
 hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool iso, bool stats, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
 hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
+// computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel
+hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,
                         int W, int H, uint32_t *out, hipStream_t s);
 

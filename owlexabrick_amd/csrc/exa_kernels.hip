@@ -631,6 +631,91 @@ __device__ void traceMeshes(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
   }
 }
 
+// ------------------------------------------------------------------------
+// streamlines: rounded-cone segments (exabrick.cu:440-570) under a BVH over the segments the
+// Streamline bounds program leaves visible; closest accepted t, lowest primitive id on a tie
+// ------------------------------------------------------------------------
+#define EXA_PRIMID_STREAMLINE (-25)
+
+__device__ __forceinline__ bool intersectRoundedCone(V3 pa, V3 pb, float ra, float rb, const Ray &ray, float &hit_t, V3 &isec_normal)
+{
+  V3 ro = ray.org;
+  const V3 rd = ray.dir;
+  const float minDist = fmaxf(0.f, fminf(length(pa - ro) - ra, length(pb - ro) - rb));
+  ro = ro + minDist * rd;
+  const V3 ba = pb - pa, oa = ro - pa;
+  const float rr = ra - rb;
+  const float m0 = dot(ba, ba), m1 = dot(ba, oa), m2 = dot(ba, rd), m3 = dot(rd, oa), m5 = dot(oa, oa);
+  const float d2 = m0 - rr * rr;
+  const float k2 = d2 - m2 * m2;
+  const float k1 = d2 * m3 - m1 * m2 + m2 * rr * ra;
+  const float k0 = d2 * m5 - m1 * m1 + m1 * rr * ra * 2.0f - m0 * ra * ra;
+  const float h = k1 * k1 - k0 * k2;
+  if (h < 0.0f) return false;
+  float t = (-sqrtf(h) - k1) / k2;
+  const float y = m1 - ra * rr + t * m2;
+  if (y > 0.0f && y < d2) {
+    hit_t = minDist + t;
+    isec_normal = d2 * (oa + t * rd) - y * ba;
+    return true;
+  }
+  const float h1 = m3 * m3 - m5 + ra * ra;                       // caps
+  if (h1 > 0.0f) {
+    t = -m3 - sqrtf(h1);
+    hit_t = minDist + t;
+    const V3 q = oa + t * rd;
+    isec_normal = mk(q.x / ra, q.y / ra, q.z / ra);
+    return true;
+  }
+  return false;
+}
+
+template <bool STATS>
+__device__ void traceStreamlines(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
+{
+  const RenderArgs &a = *C.a;
+  float best = 2e10f;                                             // streamlinePRD.t_hit (:1507)
+  int hit = -1;
+  V3 bestN = mk(0.f, 0.f, 0.f);
+  int stack[kStackDepth];
+  int sp = 0, node = 0;
+  Ray r = ray;
+  for (;;) {
+    const float4 *np = reinterpret_cast<const float4 *>(a.streamNodes + node);
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2];
+    const int4 cc = *reinterpret_cast<const int4 *>(np + 3);
+    r.tmax = fminf(ray.tmax, best);
+    float a0, a1, b0, b1;
+    boxTest(r, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), a0, a1);
+    boxTest(r, mk(q1.z, q1.w, q2.x), mk(q2.y, q2.z, q2.w), b0, b1);
+    bool ha = a0 <= a1 && q0.x <= q0.w, hb = b0 <= b1 && q1.z <= q2.y;
+    for (int side = 0; side < 2; side++) {
+      const int c = side ? cc.y : cc.x;
+      if (!(side ? hb : ha) || c >= 0 || c == INT32_MIN) continue;
+      const int prim = ~c;
+      const V3 pa = mk(a.traces + 3 * size_t(prim)), pb = mk(a.traces + 3 * (size_t(prim) + 1));
+      float th; V3 n;
+      if (!intersectRoundedCone(pa, pb, 2.f, 2.f, ray, th, n)) continue;
+      if (th >= ray.tmin && th <= ray.tmax && (th < best || (th == best && hit >= 0 && prim < hit))) { best = th; hit = prim; bestN = n; }
+    }
+    ha = ha && cc.x >= 0; hb = hb && cc.y >= 0;
+    if (ha && hb) {
+      const bool aFirst = a0 <= b0;
+      if (sp < kStackDepth) stack[sp++] = aFirst ? cc.y : cc.x;
+      node = aFirst ? cc.x : cc.y;
+    } else if (ha) node = cc.x;
+    else if (hb) node = cc.y;
+    else { if (sp == 0) break; node = stack[--sp]; }
+  }
+  if (hit >= 0 && best < prd.t_hit) {                             // :1510-1511
+    prd.primID = EXA_PRIMID_STREAMLINE;
+    prd.t_hit = best;
+    prd.Ng = normalize(bestN);
+    prd.baseColor = mk(.8f, .8f, .8f);
+    prd.ambient = 0.f;
+  }
+}
+
 // exabrick.cu:1187-1256 isoIntegrateBrick
 template <bool STATS>
 __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellValue, IsoResult &ir, float off,
@@ -722,6 +807,7 @@ __device__ __forceinline__ void traceSurfaces(Ctx<STATS> &C, const Ray &ray, Sur
         if (c.primID == EXA_PRIMID_PLANE && c.t_hit < prd.t_hit) prd = c;
       }
   }
+  if (C.a->numStreamPrims > 0) traceStreamlines(C, ray, prd);     // ST_STREAMLINES (:1503-1512)
   bool activeIso = false;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
   if (activeIso) {
@@ -775,8 +861,9 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
     V3 bgColor = mk(0.f, 0.f, 0.f);
     if (ISO) {
       traceSurfaces(C, ray, surface, true);                                       // :1601
-      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE || surface.primID == EXA_PRIMID_PLANE) {   // :1604-1652
-        const bool shade = surface.primID >= 0 || surface.primID == EXA_PRIMID_PLANE
+      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE || surface.primID == EXA_PRIMID_PLANE
+          || surface.primID == EXA_PRIMID_STREAMLINE) {   // :1604-1652
+        const bool shade = surface.primID >= 0 || surface.primID == EXA_PRIMID_PLANE || surface.primID == EXA_PRIMID_STREAMLINE
                         || (surface.primID == EXA_PRIMID_ISOSURFACE && a.p.gradientShadingISO);
         if (shade && length(surface.Ng) > 0.f) {
           const float AO_Radius = fs.ao.length;
@@ -797,7 +884,8 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
             ao_ray.tmin = 1e-4f; ao_ray.tmax = AO_Radius;
             SurfaceHit ao;
             traceSurfaces(C, ao_ray, ao, false);
-            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE) hitCnt++;
+            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE
+                || ao.primID == EXA_PRIMID_STREAMLINE) hitCnt++;
           }
           const float shadow = fs.ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
           const float fd = fabsf(dot(ray.dir, surface.Ng));
@@ -1155,6 +1243,7 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
         if (c.primID == EXA_PRIMID_PLANE && c.t_hit < prd.t_hit) prd = c;
       }
   }
+  if (C.a->numStreamPrims > 0) traceStreamlines(C, ray, prd);     // ST_STREAMLINES (:1503-1512)
   bool activeIso = false;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
   if (activeIso) {
@@ -1211,8 +1300,9 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
       SurfaceHit surface;
       traceSurfacesKd(C, ray, surface, true, stackF, qRegion, qT);
       surface_t_hit = surface.t_hit;
-      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE || surface.primID == EXA_PRIMID_PLANE) {
-        const bool shade = surface.primID >= 0 || surface.primID == EXA_PRIMID_PLANE
+      if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE || surface.primID == EXA_PRIMID_PLANE
+          || surface.primID == EXA_PRIMID_STREAMLINE) {
+        const bool shade = surface.primID >= 0 || surface.primID == EXA_PRIMID_PLANE || surface.primID == EXA_PRIMID_STREAMLINE
                         || (surface.primID == EXA_PRIMID_ISOSURFACE && a.p.gradientShadingISO);
         if (shade && length(surface.Ng) > 0.f) {
           const float AO_Radius = fs.ao.length;
@@ -1233,7 +1323,8 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
             ao_ray.tmin = 1e-4f; ao_ray.tmax = AO_Radius;
             SurfaceHit ao;
             traceSurfacesKd(C, ao_ray, ao, false, stackF, qRegion, qT);
-            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE) hitCnt++;
+            if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE
+                || ao.primID == EXA_PRIMID_STREAMLINE) hitCnt++;
           }
           const float shadow = fs.ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
           const float fd = fabsf(dot(ray.dir, surface.Ng));
@@ -1457,6 +1548,70 @@ hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, co
 {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(kdRefitKernel, dim3((count + 255) / 256), dim3(256), 0, s, nodes, nodeIds, count, active, which);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// computeTraces (exabrick.cu:1531-1574) with sampleDirection (:945-963): RK4 advection of trace i
+// through the vector field (tracerChannels), one thread per trace.  The reference runs this inside
+// renderFrame in the thread of pixel i; the new point is never read by that frame's rays (the
+// streamline BVH only holds earlier timesteps), so a separate launch gives the same traces and
+// keeps them identical on every GPU of a sharded frame.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ bool sampleDirection(Ctx<false> &C, V3 pos, V3 &result)
+{
+  Ray ray; ray.org = pos; ray.dir = mk(1.f, 1.f, 1.f); ray.tmin = 0.f; ray.tmax = 2e-10f;
+  const RegionHit prd = traceRegion(C, C.a->volNodes, ray);
+  result = mk(0.f, 0.f, 0.f);
+  if (prd.leafID < 0) return false;                               // reference: region[-1], undefined
+  const RegionInfo ri = C.a->sc.regionInfo[prd.leafID];
+  V3 unused;
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+  bool ok = samplePoint<false, false>(C, r0, unused, ri, pos, C.a->tracerChannels[0]);
+  if (ok) ok = samplePoint<false, false>(C, r1, unused, ri, pos, C.a->tracerChannels[1]);
+  if (ok) ok = samplePoint<false, false>(C, r2, unused, ri, pos, C.a->tracerChannels[2]);
+  result = mk(r0, r1, r2);
+  return ok;
+}
+
+__global__ __launch_bounds__(256) void computeTracesKernel(const RenderArgs a, float *traces, int count)
+{
+  __shared__ int stackLds[kStackDepth * 256];                     // traceRegion's per-lane stack, stride 256
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  Ctx<false> C;
+  C.a = &a; C.xfLds = nullptr; C.stack = stackLds + threadIdx.x; C.guardTripped = false;
+  if (i >= count) return;
+  const int t = a.timestep, NT = a.numTimesteps;
+  if (!(t < NT)) return;
+  V3 p = mk(traces + 3 * (size_t(i) * NT + (t - 1)));
+  const V3 pp = p;
+  if (p.x < 2e10f) {
+    bool valid = true;
+    V3 k1, k2, k3, k4;
+    valid &= sampleDirection(C, p, k1);
+    k1 = a.steplen * k1;
+    const V3 ptry1 = p + .5f * k1;
+    valid &= sampleDirection(C, ptry1, k2);
+    k2 = a.steplen * k2;
+    const V3 ptry2 = p + .5f * k2;
+    valid &= sampleDirection(C, ptry2, k3);
+    k3 = a.steplen * k3;
+    const V3 ptry3 = p + k3;
+    valid &= sampleDirection(C, ptry3, k4);
+    k4 = a.steplen * k4;
+    p = p + (1 / 6.f) * (((k1 + 2.f * k2) + 2.f * k3) + k4);
+    const bool inside = p.x >= a.worldLo[0] && p.y >= a.worldLo[1] && p.z >= a.worldLo[2]
+                     && p.x <= a.worldHi[0] && p.y <= a.worldHi[1] && p.z <= a.worldHi[2];
+    if (!valid || !inside || length(p - pp) < 1e-10f) p = mk(2e10f, 2e10f, 2e10f);
+  }
+  float *dst = traces + 3 * (size_t(i) * NT + t);
+  dst[0] = p.x; dst[1] = p.y; dst[2] = p.z;
+}
+
+hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s)
+{
+  if (count <= 0) return hipSuccess;
+  hipLaunchKernelGGL(computeTracesKernel, dim3((count + 255) / 256), dim3(256), 0, s, a, traces, count);
   return hipGetLastError();
 }
 

@@ -184,6 +184,14 @@ struct ExaHipRenderer {
   DevBuf<int32_t> meshTris;
   int numTris = 0;
 
+  // streamline tracer
+  ExaHipTracer tracer{};
+  bool haveTracer = false;
+  DevBuf<float> traces;
+  DevBuf<BvhNode> streamNodes;
+  int numStreamPrims = 0, timestep = 0;
+  bool streamDirty = false;
+
   // LBVH
   DevBuf<BvhNode> volNodes, isoNodes;
   DevBuf<int32_t> levelIds;
@@ -227,7 +235,7 @@ struct ExaHipRenderer {
     for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; i++) if (fs.contour[i].enabled) return true;
     return false;
   }
-  bool surfacesEnabled() const { return isoEnabled() || contourEnabled() || numTris > 0; }
+  bool surfacesEnabled() const { return isoEnabled() || contourEnabled() || numTris > 0 || numStreamPrims > 0; }
   float voxLo[3], voxHi[3];
   // worldSpaceBounds = rcp(voxelSpaceTransform) applied to the voxel bounds (OptixRenderer.cpp:330-332);
   // rcp(affine3f) = inverse of the linear part by adjoint/determinant, p' = -(L^-1 p)
@@ -366,8 +374,60 @@ struct ExaHipRenderer {
     return 0;
   }
 
+  // needStreamlineBVHRebuild (OptixRenderer.cpp:545-549): BVH over the segments the Streamline bounds
+  // program leaves visible (exabrick.cu:541-570), built on the host from the current traces
+  int rebuildStreamlines(hipStream_t s)
+  {
+    streamDirty = false;
+    numStreamPrims = 0;
+    if (!haveTracer) return 0;
+    const int NT = tracer.numTimesteps;
+    const long long nprims = (long long)tracer.numTraces * (NT - 1);
+    if (timestep < 2 || nprims <= 0) return 0;
+    HIP_TRY(this, hipStreamSynchronize(s));
+    std::vector<float> host(traces.n);
+    HIP_TRY(this, hipMemcpy(host.data(), traces.p, traces.n * sizeof(float), hipMemcpyDeviceToHost));
+    std::vector<float> boxes;
+    std::vector<int32_t> prim;
+    for (long long p = 0; p < nprims; p++) {
+      if (int(p % NT) >= timestep - 1) continue;
+      const float *pa = &host[3 * p], *pb = &host[3 * (p + 1)];
+      if (!(pa[0] < 2e10f && pb[0] < 2e10f)) continue;
+      for (int k = 0; k < 3; k++) boxes.push_back(std::fmin(pa[k] - 2.f, pb[k] - 2.f));
+      for (int k = 0; k < 3; k++) boxes.push_back(std::fmax(pa[k] + 2.f, pb[k] + 2.f));
+      prim.push_back((int32_t)p);
+    }
+    if (prim.empty()) return 0;
+    LbvhTopology topo;
+    topo.build(boxes.data(), prim.size());
+    const size_t ni = topo.child0.size();
+    std::vector<BvhNode> nodes(ni);
+    std::vector<float> nlo(3 * ni), nhi(3 * ni);
+    auto childBox = [&](int32_t c, float *lo, float *hi) {
+      if (c == INT32_MIN) { for (int k = 0; k < 3; k++) { lo[k] = FLT_MAX; hi[k] = -FLT_MAX; } return; }
+      if (c < 0) { for (int k = 0; k < 3; k++) { lo[k] = boxes[6 * size_t(~c) + k]; hi[k] = boxes[6 * size_t(~c) + 3 + k]; } return; }
+      for (int k = 0; k < 3; k++) { lo[k] = nlo[3 * size_t(c) + k]; hi[k] = nhi[3 * size_t(c) + k]; }
+    };
+    for (size_t i = ni; i-- > 0;) {
+      float l0[3], h0[3], l1[3], h1[3];
+      childBox(topo.child0[i], l0, h0);
+      childBox(topo.child1[i], l1, h1);
+      for (int k = 0; k < 3; k++) { nlo[3 * i + k] = std::fmin(l0[k], l1[k]); nhi[3 * i + k] = std::fmax(h0[k], h1[k]); }
+      BvhNode &n = nodes[i];
+      n.q0 = make_float4(l0[0], l0[1], l0[2], h0[0]);
+      n.q1 = make_float4(h0[1], h0[2], l1[0], l1[1]);
+      n.q2 = make_float4(l1[2], h1[0], h1[1], h1[2]);
+      auto leaf = [&](int32_t c) { return (c < 0 && c != INT32_MIN) ? ~prim[size_t(~c)] : c; };   // leaf = flat segment index
+      n.child0 = leaf(topo.child0[i]); n.child1 = leaf(topo.child1[i]); n.pad0 = n.pad1 = 0;
+    }
+    HIP_TRY(this, streamNodes.upload(nodes.data(), nodes.size()));
+    numStreamPrims = (int)prim.size();
+    return 0;
+  }
+
   int launch(uint32_t *dstDevice, bool stats, hipStream_t s)
   {
+    if (streamDirty && rebuildStreamlines(s)) return 1;
     RenderArgs a{};
     a.sc = sc;
     a.volNodes = volNodes.p;
@@ -390,6 +450,14 @@ struct ExaHipRenderer {
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
     worldBounds(a.worldLo, a.worldHi);
     a.meshNodes = meshNodes.p; a.meshVerts = meshVerts.p; a.meshTris = meshTris.p; a.numTris = numTris;
+    a.streamNodes = streamNodes.p; a.traces = traces.p; a.numStreamPrims = numStreamPrims;
+    for (int k = 0; k < 3; k++) a.tracerChannels[k] = tracer.channels[k];
+    a.numTraces = tracer.numTraces; a.numTimesteps = tracer.numTimesteps; a.timestep = timestep; a.steplen = tracer.steplen;
+    if (haveTracer && tracer.enabled && timestep < tracer.numTimesteps && timestep >= 1) {
+      // computeTraces: the threads with pixelIdx < numTraces (exabrick.cu:1539)
+      const long long px = (long long)W * H;
+      HIP_TRY(this, launchComputeTraces(a, traces.p, (int)std::min<long long>(tracer.numTraces, px), s));
+    }
     HIP_TRY(this, hipEventRecord(ev0, s));
     if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfacesEnabled(), stats, s));
     else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, surfacesEnabled(), stats, s));
@@ -663,6 +731,51 @@ int exa_hip_set_triangles(ExaHipRenderer *h, const float *vertices, uint64_t num
   HIP_TRY(h, h->meshVerts.upload(vertices, 3 * numVertices));
   HIP_TRY(h, h->meshTris.upload(triangles, 3 * numTris));
   h->numTris = (int)numTris;
+  return 0;
+}
+
+int exa_hip_reset_tracer(ExaHipRenderer *h, const ExaHipTracer *t, const float *seeds)
+{
+  if (!h || !t || !seeds) return 1;
+  if (t->numTraces < 0 || t->numTimesteps < 2 || (long long)t->numTraces * t->numTimesteps > (1ll << 28)) { h->fail("exa_hip_reset_tracer: bad trace counts"); return 1; }
+  for (int k = 0; k < 3; k++)
+    if (t->channels[k] < 0 || t->channels[k] >= h->numFields) { h->fail("exa_hip_reset_tracer: tracer channel out of range"); return 1; }
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  h->tracer = *t;
+  h->haveTracer = true;
+  std::vector<float> host(size_t(t->numTraces) * t->numTimesteps * 3, 0.f);
+  for (int i = 0; i < t->numTraces; i++) std::memcpy(&host[size_t(i) * t->numTimesteps * 3], &seeds[3 * i], 3 * sizeof(float));
+  HIP_TRY(h, h->traces.upload(host.data(), host.size()));
+  h->timestep = 0;
+  h->streamDirty = true;                     // needStreamlineBVHRebuild = true (:461)
+  return 0;
+}
+
+int exa_hip_set_tracer_enabled(ExaHipRenderer *h, int32_t enabled)
+{
+  if (!h) return 1;
+  h->tracer.enabled = enabled;
+  return 0;
+}
+
+int exa_hip_advance_tracer(ExaHipRenderer *h, int32_t *rebuild)
+{
+  if (!h) return 1;
+  if (rebuild) *rebuild = 0;
+  if (!h->haveTracer || !h->tracer.enabled) return 0;
+  h->timestep++;
+  if (h->timestep <= h->tracer.numTimesteps) h->streamDirty = true;
+  if (rebuild) *rebuild = h->streamDirty;
+  return 0;
+}
+
+int exa_hip_read_traces(ExaHipRenderer *h, float *dst)
+{
+  if (!h || !dst || !h->haveTracer) return 1;
+  HIP_TRY(h, hipSetDevice(h->device));
+  HIP_TRY(h, hipDeviceSynchronize());
+  HIP_TRY(h, hipMemcpy(dst, h->traces.p, h->traces.n * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <random>
 #include <stack>
 #include <stdexcept>
 
@@ -342,6 +343,7 @@ Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP> surfaces, std
     handle = nullptr; prep = nullptr;
     throw std::runtime_error(msg);
   }
+  if (fields.size() >= 3) resetTracer();          // the constructor's resetTracer() (:288); needs three velocity fields
   params.dt = 0.5f;
   params.numPrimaryChannels = multiFieldDvr ? (int)fields.size() : 1;                 // :284
   params.colormapChannel = (!multiFieldDvr && fields.size() > 1) ? 1 : 0;             // :278-283
@@ -412,9 +414,38 @@ void Renderer::updateDt(float dt) { params.dt = dt; }
 void Renderer::setSpaceSkipping(bool e) { doSpaceSkipping = e; }
 void Renderer::setGradientShadingDVR(bool e) { gradientShadingDVR = e; }
 void Renderer::setGradientShadingISO(bool e) { gradientShadingISO = e; }
-void Renderer::setTracerEnabled(bool) {}
-void Renderer::resetTracer() {}
-bool Renderer::advanceTracer() { return false; }
+void Renderer::setTracerEnabled(bool e)
+{
+  traces.tracerEnabled = e;
+  check(exa_hip_set_tracer_enabled(handle, e), handle);
+}
+
+// OptixRenderer::resetTracer (exa/OptixRenderer.cpp:450-472): seeds drawn inside seedRegion * size
+void Renderer::resetTracer()
+{
+  const vec3f size = voxelSpaceBounds.upper - voxelSpaceBounds.lower;
+  std::default_random_engine engine(0);
+  std::uniform_real_distribution<float> x(traces.seedRegion.lower.x * size.x, traces.seedRegion.upper.x * size.x);
+  std::uniform_real_distribution<float> y(traces.seedRegion.lower.y * size.y, traces.seedRegion.upper.y * size.y);
+  std::uniform_real_distribution<float> z(traces.seedRegion.lower.z * size.z, traces.seedRegion.upper.z * size.z);
+  std::vector<float> seeds(size_t(traces.numTraces) * 3);
+  for (int i = 0; i < traces.numTraces; ++i) { seeds[3 * i] = x(engine); seeds[3 * i + 1] = y(engine); seeds[3 * i + 2] = z(engine); }
+  ExaHipTracer t;
+  t.enabled = traces.tracerEnabled;
+  t.channels[0] = traces.tracerChannels.x; t.channels[1] = traces.tracerChannels.y; t.channels[2] = traces.tracerChannels.z;
+  t.numTraces = traces.numTraces; t.numTimesteps = traces.numTimesteps; t.steplen = traces.steplen;
+  check(exa_hip_reset_tracer(handle, &t, seeds.data()), handle);
+  traces.timestepHost = 0;
+}
+
+bool Renderer::advanceTracer()
+{
+  if (!traces.tracerEnabled) return false;
+  int32_t rebuild = 0;
+  check(exa_hip_advance_tracer(handle, &rebuild), handle);
+  traces.timestepHost++;
+  return rebuild != 0;
+}
 
 void Renderer::pushState()
 {

@@ -164,7 +164,7 @@ struct Renderer {
   void setSpaceSkipping(bool enable);
   void setGradientShadingDVR(bool enable);
   void setGradientShadingISO(bool enable);
-  void setTracerEnabled(bool enable);    // streamline tracer: SURVEY 8f row, accepted and ignored
+  void setTracerEnabled(bool enable);
   void resetTracer();
   bool advanceTracer();
   void render();
@@ -179,6 +179,15 @@ struct Renderer {
   bool doSpaceSkipping = true;
   FrameState frameState;
   vec2i fbSize;
+  struct {                                   // exa/OptixRenderer.h:160-170
+    int tracerEnabled = false;
+    vec3i tracerChannels{ 0, 1, 2 };
+    int numTraces = 1000;
+    int numTimesteps = 100;
+    float steplen = 1e-6f;
+    int timestepHost = 0;
+    box3f seedRegion{ vec3f(.3f, .3f, .5f), vec3f(.8f, .8f, .5f) };
+  } traces;
 
 private:
   void pushState();
