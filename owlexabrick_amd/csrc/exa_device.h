@@ -50,6 +50,7 @@ static_assert(sizeof(RegionRec) == 48, "region record = three 16-byte loads");
 struct DeviceScene {
   const int4       *bricks;        // ExaBrick as two int4: (lower.xyz,size.x) (size.yz,level,begin)
   const int32_t    *leafList;
+  const int4       *leafHdr;       // brick records repeated along the leaf list (two int4 per entry)
   const float      *scalars;
   const RegionInfo *regionInfo;
   const float2     *valueRange;    // per region

@@ -1005,7 +1005,7 @@ struct Packed {
   __device__ __forceinline__ int get(int sh) const { return (v >> sh) & 15; }
   __device__ __forceinline__ void set(int sh, int x) { v = (v & ~(15u << sh)) | ((unsigned)x << sh); }
 };
-enum { PK_SHEAD = 0, PK_SCOUNT = 4, PK_DROPPED = 8, PK_QHEAD = 12, PK_QCOUNT = 16 };
+enum { PK_SHEAD = 0, PK_SCOUNT = 4, PK_DROPPED = 8, PK_QHEAD = 12, PK_QCOUNT = 16, PK_NEEDHDR = 20 };
 
 struct KdWalk {
   int   ref;            // current subtree reference, or KD_DONE
@@ -1372,10 +1372,10 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
 
     // ---- segment / sample state ----
     bool haveSeg = false;
-    int listBegin = 0, listSize = 0, firstBrick = 0;
+    int listBegin = 0, listSize = 0;
     float flcw = 1.f;                     // region.finestLevelCellWidth; dt = launch.dt * flcw (:1129)
     float t1 = 0.f, t_i = 0.f, t_last = 0.f, t_sample = 0.f, actual_dt = 0.f;
-    int child = 0, chan = 0, brickID = 0, loadedBrick = -1;      // chan stays 0 (and folds away) unless MULTI
+    int child = 0, chan = 0;                                     // chan stays 0 (and folds away) unless MULTI
     int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 0, 0);
     Basis B;
     B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
@@ -1406,11 +1406,11 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
         {
           const RegionInfo ri = a.sc.regionInfo[region];
           listBegin = ri.listBegin; listSize = ri.listSize;
-          firstBrick = ri.firstBrick;
           flcw = ri.finestLevelCellWidth;
         }
         C.count(ST_SEGMENTS);
         haveSeg = true;
+        w.pk.set(PK_NEEDHDR, 1);
         t_i = firstSampleT(t0, a.p.dt * flcw, interleavedSamplingOffset);          // :1141-1144
         // first step of the segment (:1158-1166)
         {
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
           actual_dt = t_next - t0;
           t_last = t_next;
         }
-        child = 0; brickID = firstBrick;
+        child = 0;
         if (MULTI) { chan = 0; field = field0; }
         B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
         C.count(ST_SAMPLE_EVALS);
@@ -1427,13 +1427,16 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
 
       // ---- one brick visit ----
       C.phase(ST_W_BRICK);
-      if (brickID != loadedBrick) {
-        hb0 = a.sc.bricks[2 * brickID]; hb1 = a.sc.bricks[2 * brickID + 1];
-        loadedBrick = brickID;
+      // brick records are stored along the leaf list (no id indirection); a one-brick region keeps the
+      // record it loaded at the start of the segment
+      if (listSize > 1 || w.pk.get(PK_NEEDHDR)) {
+        const unsigned at = 2u * (unsigned)(listBegin + child);
+        hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
+        w.pk.set(PK_NEEDHDR, 0);
       }
       addBasisFast<GRAD, STATS>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
       child++;
-      if (child < listSize) { brickID = a.sc.leafList[listBegin + child]; continue; }
+      if (child < listSize) continue;
 
       // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
       C.phase(ST_W_FINAL);
@@ -1447,7 +1450,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
         integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, (int)flcw, MULTI ? chan : 0);
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
-      child = 0; brickID = firstBrick;
+      child = 0;
       if (MULTI) {
         chan++;
         if (chan < numChannels) {

@@ -161,6 +161,7 @@ struct ExaHipRenderer {
   // scene
   DevBuf<int4> bricks;
   DevBuf<int32_t> leafList;
+  DevBuf<int4> leafHdr;
   DevBuf<float> scalars;
   DevBuf<RegionInfo> regionInfo;
   DevBuf<float2> valueRange;
@@ -509,6 +510,11 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   static_assert(sizeof(ExaBrick) == 2 * sizeof(int4), "brick = two int4");
   CREATE_TRY(h->bricks.upload(reinterpret_cast<const int4 *>(scene->bricks), scene->numBricks * 2));
   CREATE_TRY(h->leafList.upload(scene->leafList, scene->leafListSize));
+  {
+    std::vector<ExaBrick> hdr(scene->leafListSize);
+    for (uint64_t i = 0; i < scene->leafListSize; i++) hdr[i] = scene->bricks[scene->leafList[i]];
+    CREATE_TRY(h->leafHdr.upload(reinterpret_cast<const int4 *>(hdr.data()), hdr.size() * 2));
+  }
   CREATE_TRY(h->scalars.upload(scene->scalars, size_t(scene->numFields) * scene->totalCells));
   std::vector<RegionInfo> ri(scene->numRegions);
   std::vector<float2> vr(scene->numRegions);
@@ -630,6 +636,7 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
 
   h->sc.bricks = h->bricks.p;
   h->sc.leafList = h->leafList.p;
+  h->sc.leafHdr = h->leafHdr.p;
   h->sc.scalars = h->scalars.p;
   h->sc.regionInfo = h->regionInfo.p;
   h->sc.valueRange = h->valueRange.p;
