@@ -261,6 +261,9 @@ __device__ __forceinline__ void addBasisFunctions(Ctx<STATS> &C, Basis &B, const
 #undef EXA_CORNER
 }
 
+struct __attribute__((packed, aligned(4))) Pair { float a, b; };
+__device__ __forceinline__ Pair loadPair(const float *__restrict__ p) { return *reinterpret_cast<const Pair *>(p); }
+
 // Same sums as addBasisFunctions with fewer instructions: validity is a product of
 // per-axis predicates, so the per-axis weights are masked to 0 once (6 selects) instead of
 // selecting every accumulator at every corner.  A skipped corner then adds +-0, which
@@ -289,10 +292,16 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const uint32_t zl = (uint32_t)b1.w + (uint32_t)czl * sxy, zh = (uint32_t)b1.w + (uint32_t)czh * sxy;
   const uint32_t yl = (uint32_t)(cyl * sx), yh = (uint32_t)(cyh * sx);
   const uint32_t rowLL = zl + yl, rowHL = zl + yh, rowLH = zh + yl, rowHH = zh + yh;
-  const float s000 = field[rowLL + cxl], s100 = field[rowLL + cxh];
-  const float s010 = field[rowHL + cxl], s110 = field[rowHL + cxh];
-  const float s001 = field[rowLH + cxl], s101 = field[rowLH + cxh];
-  const float s011 = field[rowHH + cxl], s111 = field[rowHH + cxh];
+  // the two x-neighbours of a row are adjacent in memory: one 8-byte load per row (4-byte
+  // aligned), then pick the clamped low/high cell out of the pair
+  const int bx = min(max(lx, 0), max(sx - 2, 0));
+  const bool lFirst = cxl == bx, hFirst = cxh == bx;
+  const Pair pLL = loadPair(field + rowLL + bx), pHL = loadPair(field + rowHL + bx);
+  const Pair pLH = loadPair(field + rowLH + bx), pHH = loadPair(field + rowHH + bx);
+  const float s000 = lFirst ? pLL.a : pLL.b, s100 = hFirst ? pLL.a : pLL.b;
+  const float s010 = lFirst ? pHL.a : pHL.b, s110 = hFirst ? pHL.a : pHL.b;
+  const float s001 = lFirst ? pLH.a : pLH.b, s101 = hFirst ? pLH.a : pLH.b;
+  const float s011 = lFirst ? pHH.a : pHH.b, s111 = hFirst ? pHH.a : pHH.b;
   C.count(ST_BRICK_VISITS);
   if (STATS) C.st[ST_CORNER_LOADS] += (unsigned)((int(vlx) + int(vhx)) * (int(vly) + int(vhy)) * (int(vlz) + int(vhz)));
   // masked per-axis weights: (1-frac) for the low cell, frac for the high cell

@@ -139,7 +139,8 @@ struct DevBuf {
     release();
     n = count;
     if (count == 0) return hipSuccess;
-    return hipMalloc((void **)&p, count * sizeof(T));
+    // 16 spare bytes: the pair load of a one-cell-wide row reads one float past the last brick
+    return hipMalloc((void **)&p, count * sizeof(T) + 16);
   }
   hipError_t upload(const T *src, size_t count)
   {
