@@ -97,6 +97,8 @@ struct RenderArgs {
   const int32_t     *tileMap;       // blockIdx.x -> global tile id (launch order)
   uint32_t          *color;
   float4            *accum;
+  float4            *surf;          // surfaces pre-pass -> march: {background rgb, surface t_hit} per pixel slot
+  uint32_t          *surfRnd;       // LCG state after the pre-pass' draws
   unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
   int32_t           *errorFlag;     // set when a loop guard trips
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)

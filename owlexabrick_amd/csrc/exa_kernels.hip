@@ -730,6 +730,9 @@ template <bool STATS>
 __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellValue, IsoResult &ir, float off,
                                   const Ray &ray, const RegionInfo &ri, float t0, float t1, int numChannels)
 {
+  unsigned isoChannelMask = 0;
+  for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++)
+    if (C.a->fs.iso[i].enabled) isoChannelMask |= 1u << (C.a->fs.iso[i].channel & 31);
   const float dt = C.a->p.dt * ri.finestLevelCellWidth;
   float t_i = firstSampleT(t0, dt, off);
   float t_last = t0;
@@ -740,6 +743,11 @@ __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellV
     t_last = t_next;
     const V3 pos = ray.org + t_sample * ray.dir;
     for (int c = 0; c < numChannels; ++c) {
+      // A channel no enabled iso-surface refers to only feeds last_t/lastCellValue[c], which nothing
+      // reads; its sample matters solely through the `break` below once the segment already holds an
+      // opaque hit.  Outside that case it is skipped (the instrumented variant keeps the reference's
+      // full count of evaluations).
+      if (!STATS && !((isoChannelMask >> c) & 1u) && ir.pixelColor.w < EXA_TERMINATION_THRESHOLD) continue;
       float cellValue = 0.f;
       V3 grad = mk(0.f, 0.f, 0.f);
       bool doIntegrate;
@@ -1261,8 +1269,15 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
   }
 }
 
-template <bool GRAD, bool FAST, bool MULTI, bool ISO, bool STATS>
-__global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderFrameKdKernel(const RenderArgs a)
+// ------------------------------------------------------------------------
+// Surfaces pre-pass (exabrick.cu:1601-1652): triangle meshes, contour planes, streamlines and the
+// implicit iso-surface march, shading and AO rays.  Runs as its own launch in front of the volume
+// march when a frame has surfaces, and hands {background colour, surface t_hit} and the LCG state
+// to it through a[].surf / surfRnd: the generic surface code needs ~130 VGPRs, the march 80, and one
+// fused kernel would run the march at half its occupancy.
+// ------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(kKdBlock, 3) void surfacePrepassKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -1305,7 +1320,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
     // ---- surfaces first: implicit iso-surface hit, AO rays, background colour (:1601-1652) ----
     V3 bgColor = mk(0.f, 0.f, 0.f);
     float surface_t_hit = ray.tmax;
-    if (ISO) {
+    {
       SurfaceHit surface;
       traceSurfacesKd(C, ray, surface, true, stackF, qRegion, qT);
       surface_t_hit = surface.t_hit;
@@ -1345,6 +1360,71 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
           bgColor = surface.baseColor;
         }
       }
+    }
+    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
+                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+    a.surf[slot] = make_float4(bgColor.x, bgColor.y, bgColor.z, surface_t_hit);
+    a.surfRnd[slot] = rnd.state;
+  }
+
+  if (C.guardTripped) atomicExch(a.errorFlag, 1);
+  if (STATS) {
+    for (int i = 0; i < ST_COUNT; i++) {
+      unsigned long long v = inside ? C.st[i] : 0ull;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+      if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.stats[i], v);
+    }
+  }
+}
+
+template <bool GRAD, bool FAST, bool MULTI, bool SURF, bool STATS>
+__global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel(const RenderArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *xfLds = reinterpret_cast<float4 *>(smem);
+  unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
+  int *stackRef = reinterpret_cast<int *>(sp0);
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
+  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
+  __syncthreads();
+
+  Ctx<STATS> C;
+  C.a = &a;
+  C.xfLds = xfLds;
+  C.stack = stackRef + threadIdx.x;
+  C.guardTripped = false;
+  if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
+
+  // a workgroup is kKdBlock/64 waves; each wave renders one 8x8 block of a 16x16 tile
+  const int wavesPerBlock = kKdBlock / 64;
+  const int gwave = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6);
+  const int tile = a.tileMap[gwave >> 2];
+  const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+  const int wave = gwave & 3, lane = threadIdx.x & 63;
+  const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
+  const int px = tx * kTile + inX, py = ty * kTile + inY;
+  const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
+
+  if (inside) {
+    const ExaHipFrameState &fs = a.fs;
+    const int frameID = fs.frameID;
+    Lcg rnd;
+    rnd.init((uint32_t)(frameID * a.W * a.H) + (uint32_t)px, (uint32_t)py);      // :1591-1592
+    const float sx = float(px) + rnd.next();
+    const float sy = float(py) + rnd.next();
+    Ray ray;
+    ray.org = mk(fs.cam_pos);
+    ray.dir = normalize((mk(fs.cam_dir00) + sx * mk(fs.cam_dirDu)) + sy * mk(fs.cam_dirDv));
+    ray.tmin = 1e-6f; ray.tmax = 1e8f;
+    // ---- surfaces: results of the pre-pass launch (the background colour is fetched after the march) ----
+    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
+                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+    float surface_t_hit = ray.tmax;
+    if (SURF) {
+      surface_t_hit = a.surf[slot].w;
+      rnd.state = a.surfRnd[slot];
     }
     const float interleavedSamplingOffset = rnd.next();                           // :1655
     ray.tmax = surface_t_hit;                                                     // :1657-1659
@@ -1491,11 +1571,11 @@ __global__ __launch_bounds__(kKdBlock, (ISO ? 3 : (MULTI ? 5 : 6))) void renderF
       C.count(ST_SAMPLE_EVALS);
     }
 
+    float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (SURF) bgColor = a.surf[slot];
     float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
     float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
     float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
-    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
-                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
     if (frameID > 0) {
       const float4 acc = a.accum[slot];
       cr += acc.x; cg += acc.y; cb += acc.z;
@@ -1522,6 +1602,10 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   const bool multi = a.p.numPrimaryChannels > 1;
+  if (iso) {
+    if (stats) hipLaunchKernelGGL((surfacePrepassKdKernel<true>), grid, block, lds, s, a);
+    else       hipLaunchKernelGGL((surfacePrepassKdKernel<false>), grid, block, lds, s, a);
+  }
 #define EXA_LAUNCH(G, F, M, I, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S>), grid, block, lds, s, a)
 #define EXA_PICK2(G, F, M, I) do { if (stats) EXA_LAUNCH(G, F, M, I, true); else EXA_LAUNCH(G, F, M, I, false); } while (0)
 #define EXA_PICK(G, F, M) do { if (iso) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)

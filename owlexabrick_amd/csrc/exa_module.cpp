@@ -217,6 +217,8 @@ struct ExaHipRenderer {
   int debugPixel = -1;
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
   DevBuf<float4> accum;
+  DevBuf<float4> surf;
+  DevBuf<uint32_t> surfRnd;
   DevBuf<uint32_t> color;
   DevBuf<int32_t> tileMap;
   int numBlocks = 0;
@@ -273,6 +275,7 @@ struct ExaHipRenderer {
     HIP_TRY(this, accum.alloc(px));
     if (px) HIP_TRY(this, hipMemset(accum.p, 0, px * sizeof(float4)));
     HIP_TRY(this, color.alloc(px));
+    surf.release(); surfRnd.release();       // allocated by the first frame that has surfaces
     std::vector<int32_t> map;
     map.reserve(numBlocks);
     for (int t = rank; t < tilesX * tilesY; t += world) map.push_back(t);
@@ -443,6 +446,8 @@ struct ExaHipRenderer {
     a.tileMap = tileMap.p;
     a.color = dstDevice;
     a.accum = accum.p;
+    a.surf = surf.p;
+    a.surfRnd = surfRnd.p;
     a.stats = statsBuf.p;
     a.errorFlag = errorFlag.p;
     a.debugPixel = debugPixel;
@@ -459,6 +464,11 @@ struct ExaHipRenderer {
       // computeTraces: the threads with pixelIdx < numTraces (exabrick.cu:1539)
       const long long px = (long long)W * H;
       HIP_TRY(this, launchComputeTraces(a, traces.p, (int)std::min<long long>(tracer.numTraces, px), s));
+    }
+    if (useKd() && surfacesEnabled() && surf.n != accum.n) {
+      HIP_TRY(this, surf.alloc(accum.n));
+      HIP_TRY(this, surfRnd.alloc(accum.n));
+      a.surf = surf.p; a.surfRnd = surfRnd.p;
     }
     HIP_TRY(this, hipEventRecord(ev0, s));
     if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfacesEnabled(), stats, s));

@@ -55,6 +55,12 @@ CASES = {
                             W=128, H=128, grad=1),
     "amr_2ch_colormap": lambda: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2),
                                      W=96, H=96, grad=1, multi=False, iso=[(0.5, 0)]),
+    # iso-surfaces on the second of two primary channels only / on both: the march skips the
+    # iso sampling of channels nothing refers to (until a segment holds an opaque hit)
+    "amr_2ch_iso_ch1": lambda: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2),
+                                    W=96, H=96, grad=1, iso=[(0.35, 1), (0.65, 1)]),
+    "amr_2ch_iso_both": lambda: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2),
+                                     W=96, H=96, grad=0, iso=[(0.5, 0), (0.4, 1)]),
     "amr_xfm": lambda: Case(_amr(), W=96, H=96, grad=1,
                             xfm=dict(vx=[48, 0, 0], vy=[0, 48, 0], vz=[0, 0, 32], p=[0, 0, 0]),
                             camera=([0.2, 1.7, 2.0], [0.5, 0.5, 0.5], [0, 1, 0], 60.0)),
@@ -94,6 +100,18 @@ def test_hip_matches_oracle(name, accel):
     assert r["accum_bad"] == 0 and r["rgba_bad"] == 0, r
     assert {k: o[2][k] for k in STAT_KEYS} == {k: h[2][k] for k in STAT_KEYS}   # identical work, sample for sample
     assert h[2]["diag"][8] == 0        # kd interval == the reference's slab test, every leaf
+
+
+@pytest.mark.parametrize("fast_math", [0, 1])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_shipped_kernel_equals_instrumented_variant(name, fast_math):
+    """the parity tests above run the counting variant of the kernels; the variant a caller gets from
+    exa_hip_render must produce the same accumulation buffer bit for bit"""
+    case = CASES[name]()
+    case.fast_math = fast_math
+    plain, counted = case.run_hip(), case.run_hip(stats=True)
+    assert np.array_equal(plain[1].view(np.uint32), counted[1].view(np.uint32))
+    assert np.array_equal(plain[0], counted[0])
 
 
 @pytest.mark.parametrize("name", ["ex3_grad", "c1_64", "amr_grad", "amr_band", "amr_2ch", "amr_inside", "gen_exajet"])
