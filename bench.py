@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--accel", type=int, default=int(os.environ.get("EXA_ACCEL", "1")),
                     help="1 = region kd-tree walked front to back (default), 0 = LBVH restarted per segment")
     ap.add_argument("--iso", type=float, default=None, help="enable one implicit iso-surface at this value (channel 0)")
+    ap.add_argument("--ao", action="store_true", help="ambient-occlusion rays on surface hits (2 per hit, reference default)")
+    ap.add_argument("--spp", type=int, default=1, help="frames accumulated per step (frameID 0..spp-1); a step is one converged frame")
     ap.add_argument("--dump", default=None, help="write the frame as PNG (rank 0)")
     args = ap.parse_args()
 
@@ -99,7 +101,7 @@ def main():
     # the CPU baseline needs the oracle's own scene (its own region build, serial C);
     # start it now on one core so it overlaps the GPU part
     oracle_box = {}
-    want_cpu = args.cpu_baseline == "auto" and rank == 0 and world == 1
+    want_cpu = args.cpu_baseline == "auto" and rank == 0 and world == 1 and args.iso is None and args.spp == 1
 
     def build_oracle():
         from oracle import pyoracle as po          # bench.py's cpu_baseline leg may use the oracle
@@ -138,7 +140,7 @@ def main():
     R.setSpaceSkipping(True)
     R.setGradientShadingDVR(not args.no_grad)
     R.updateDt(0.5)
-    R.frameState.ao.enabled = 0
+    R.frameState.ao.enabled = 1 if args.ao else 0
     R.updateFrameID(0)
 
     n_out = R.outputPixels()
@@ -153,10 +155,12 @@ def main():
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
-        if world == 1:
+        for f in range(args.spp):                                      # viewer.cpp:279-288, one launch per sample
+            if args.spp > 1:
+                R.updateFrameID(f)
             R.render(device_ptr=shard.data_ptr(), stream=stream)       # synchronous, like owlLaunch2D
+        if world == 1:
             return
-        R.render(device_ptr=shard.data_ptr(), stream=stream)
         if backend == "nccl":
             if mode["collective"] == "gather":
                 try:
@@ -176,7 +180,8 @@ def main():
         if rank == 0:
             R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=stream)
 
-    # work counters of this frame (instrumented kernel variant, same frameID)
+    # work counters of this frame (instrumented kernel variant, frameID 0)
+    R.updateFrameID(0)
     _, st = R.renderStats()
     log("stats:", {k: v for k, v in st.items() if k not in ("kernel_ms", "rebuild_ms")})
 
@@ -189,7 +194,7 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(R.stats()["kernel_ms"])
+        kernel_ms.append(R.stats()["kernel_ms"])       # the step's last launch
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -214,12 +219,13 @@ def main():
         B = algorithmic_bytes(st, st["pixels"], 0)         # per launch of this rank
         achieved = B / (k_ms * 1e-3) / 1e9
         out = {
-            "metric": f"frames/sec at {W}^2 DVR{'+iso' if args.iso is not None else ''}, {args.config.split('_', 1)[1]}-like, MI355X",
+            "metric": f"frames/sec at {W}^2 DVR{'+iso' if args.iso is not None else ''}{'+AO' if args.ao else ''}"
+                      f"{', %d spp' % args.spp if args.spp > 1 else ''}, {args.config.split('_', 1)[1]}-like, MI355X",
             "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "msamples_per_s": samples_total / 1e6 * fps,
+            "msamples_per_s": samples_total / 1e6 * fps * args.spp,
             "config": {"workload": f"{args.config} (seed 0xE7A0003 procedural AMR, scale {args.scale}): "
                                    f"{scene.num_cells} cells / {scene.bricks7.shape[0]} bricks / "
                                    f"{int(prep.scene.numRegions)} regions, {W}x{H} DVR, dt 0.5, alpha ramp, "
