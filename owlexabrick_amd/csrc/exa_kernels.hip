@@ -1068,9 +1068,11 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
                                        float *stackF, int *qRegion, float *qT, const Ray &ray, const int which,
                                        float &walkTmax, const float dtScale)
 {
+  // A call runs up to three stages in a row — leaf, pop, node — so that a lane that has just
+  // queued a leaf also takes the next node in the same call (the wave executes all three
+  // stages for its divergent lanes anyway; fewer calls per burst).
   if (ISOWALK && w.ref != EXA_KD_EMPTY && !(w.tn < walkTmax)) { w.ref = EXA_KD_DONE; return; }   // everything left lies beyond tmax
-  if (w.ref == EXA_KD_EMPTY || !(w.tf > walkTmin)) { kdPop(C, w, a, stackF); return; }
-  if (w.ref < 0) {
+  if (w.ref < 0 && w.ref > EXA_KD_DONE && w.tf > walkTmin) {
     // Leaf.  Its interval [w.tn, w.tf] is max/min over exactly the plane distances the
     // reference's slab test (exabrick.cu:197-210, 213-238) evaluates for this region's domain,
     // (plane-o)/d each: the faces are split planes of the path (or faces of the root box) and
@@ -1102,9 +1104,10 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
       if (ISOWALK) walkTmax = walkTmax * dtScale;            // the next trace's tmax (:1434)
     }
     w.ref = EXA_KD_EMPTY;
-    kdPop(C, w, a, stackF);
-    return;
   }
+  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop(C, w, a, stackF);
+  // the popped subtree gets its own look at tmin / tmax in the next call
+  if (w.ref < 0 || !(w.tf > walkTmin) || (ISOWALK && !(w.tn < walkTmax))) return;
   const int4 n = *reinterpret_cast<const int4 *>(a.kdNodes + w.ref);
   C.count(ST_NODES);
   C.phase(ST_W_NODE);
