@@ -1511,9 +1511,8 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
           actual_dt = t_next - t0;
           t_last = t_next;
         }
-        child = 0;
-        if (MULTI) { chan = 0; field = field0; }
-        B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+        // child, chan/field and the basis sums are already at their start values here: the sample
+        // epilogue resets them, and a segment only ends there
         C.count(ST_SAMPLE_EVALS);
       }
 
@@ -1550,6 +1549,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
           C.count(ST_SAMPLE_EVALS);
           continue;
         }
+        chan = 0; field = field0;
       }
       // ---- end of this step (:1180-1183) ----
       if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) {
@@ -1570,7 +1570,6 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         actual_dt = t_next - t_last;
         t_last = t_next;
       }
-      if (MULTI) { chan = 0; field = field0; }
       C.count(ST_SAMPLE_EVALS);
     }
 
