@@ -120,7 +120,7 @@ def main():
     R = binding.Renderer(prep, device=local_rank)
     t_up = time.time() - t0
     log(f"prep {t_prep:.1f}s ({prep.scene.numRegions} regions, {prep.scene.leafListSize} leaf entries), "
-        f"upload+LBVH {t_up:.1f}s")
+        f"upload {t_up:.1f}s")
 
     lo, hi = prep.voxel_bounds()
     cam = harness.default_camera(lo, hi, W, H)                 # exa/viewer.cpp:1289-1294

@@ -333,6 +333,48 @@ struct ExaHipRenderer {
   }
   bool useKd() const { return haveKd && accel == 1; }
 
+  // The LBVH over the regions (north_star's structure; accel=0, scenes without a kd-tree, and the
+  // streamline tracer's point queries) is built on first use: Morton-sorted regions, topology on the
+  // host from the region domains read back from the device, boxes filled by the refit.
+  bool lbvhBuilt = false;
+  int ensureLbvh()
+  {
+    if (lbvhBuilt) return 0;
+    const size_t nr = domain.n / 6;
+    std::vector<float> boxes(domain.n);
+    HIP_TRY(this, hipMemcpy(boxes.data(), domain.p, domain.n * sizeof(float), hipMemcpyDeviceToHost));
+    LbvhTopology topo;
+    topo.build(boxes.data(), nr);
+    boxes.clear(); boxes.shrink_to_fit();
+    const size_t ni = topo.child0.size();
+    topoTemplate.resize(ni);
+    for (size_t i = 0; i < ni; i++) {
+      BvhNode &n = topoTemplate[i];
+      n.q0 = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX);
+      n.q1 = make_float4(-FLT_MAX, -FLT_MAX, FLT_MAX, FLT_MAX);
+      n.q2 = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+      n.child0 = topo.child0[i]; n.child1 = topo.child1[i]; n.pad0 = n.pad1 = 0;
+    }
+    HIP_TRY(this, volNodes.upload(topoTemplate.data(), ni));
+    int maxH = 0;
+    for (size_t i = 0; i < ni; i++) maxH = std::max(maxH, topo.height[i]);
+    std::vector<int> count(maxH + 2, 0);
+    for (size_t i = 0; i < ni; i++) count[topo.height[i]]++;
+    levelBegin.assign(1, 0);
+    for (int hh = 1; hh <= maxH; hh++) levelBegin.push_back(levelBegin.back() + count[hh]);
+    std::vector<int32_t> ids(ni);
+    {
+      std::vector<int> cursor(levelBegin.begin(), levelBegin.end());
+      for (size_t i = 0; i < ni; i++) ids[cursor[topo.height[i] - 1]++] = (int32_t)i;
+    }
+    HIP_TRY(this, levelIds.upload(ids.data(), ids.size()));
+    sc.numInternal = (uint32_t)ni;
+    lbvhBuilt = true;
+    volDirty = isoDirty = true;          // boxes of both LBVHs come from the next refit
+    return 0;
+  }
+  bool needLbvh() const { return !useKd() || (haveTracer && tracer.enabled); }
+
   int refit(DevBuf<BvhNode> &nodes, const uint8_t *active, hipStream_t s)
   {
     for (size_t h = 0; h + 1 < levelBegin.size(); h++) {
@@ -355,20 +397,21 @@ struct ExaHipRenderer {
       HIP_TRY(this, hipMemcpyAsync(xf.p, xfHost, sizeof(xfHost), hipMemcpyHostToDevice, s));
       xfDirty = false;
     }
+    if (needLbvh() && ensureLbvh()) return 1;
     const bool needIso = isoEnabled();
     if (volDirty || (needIso && isoDirty)) {
       HIP_TRY(this, hipEventRecord(ev2, s));
       if (volDirty) {                       // needVolumeBVHRebuild (OptixRenderer.cpp:533-537)
         HIP_TRY(this, launchVolumeActivity(sc, fs, p, xf.p, volActive.p, s));
-        if (refit(volNodes, volActive.p, s)) return 1;
+        if (lbvhBuilt && refit(volNodes, volActive.p, s)) return 1;
         if (haveKd && kdRefit(volActive.p, 0, s)) return 1;
         volDirty = false;
       }
       if (needIso && isoDirty) {            // needIsoBVHRebuild (OptixRenderer.cpp:539-543)
-        if (!isoNodes.p && !topoTemplate.empty())
+        if (lbvhBuilt && !isoNodes.p && !topoTemplate.empty())
           HIP_TRY(this, isoNodes.upload(topoTemplate.data(), topoTemplate.size()));
         HIP_TRY(this, launchIsoActivity(sc, fs, isoActive.p, s));
-        if (refit(isoNodes, isoActive.p, s)) return 1;
+        if (lbvhBuilt && refit(isoNodes, isoActive.p, s)) return 1;
         if (haveKd && kdRefit(isoActive.p, 1, s)) return 1;
         isoDirty = false;
       }
@@ -546,31 +589,6 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   CREATE_TRY(h->valueRange.upload(vr.data(), vr.size()));
   CREATE_TRY(h->domain.upload(dom.data(), dom.size()));
 
-  // LBVH topology (host), boxes are filled by the first refit
-  LbvhTopology topo;
-  topo.build(scene->regions, scene->numRegions);
-  const size_t ni = topo.child0.size();
-  h->topoTemplate.resize(ni);
-  for (size_t i = 0; i < ni; i++) {
-    BvhNode &n = h->topoTemplate[i];
-    n.q0 = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX);
-    n.q1 = make_float4(-FLT_MAX, -FLT_MAX, FLT_MAX, FLT_MAX);
-    n.q2 = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-    n.child0 = topo.child0[i]; n.child1 = topo.child1[i]; n.pad0 = n.pad1 = 0;
-  }
-  CREATE_TRY(h->volNodes.upload(h->topoTemplate.data(), ni));
-  int maxH = 0;
-  for (size_t i = 0; i < ni; i++) maxH = std::max(maxH, topo.height[i]);
-  std::vector<int> count(maxH + 2, 0);
-  for (size_t i = 0; i < ni; i++) count[topo.height[i]]++;
-  h->levelBegin.assign(1, 0);
-  for (int hh = 1; hh <= maxH; hh++) h->levelBegin.push_back(h->levelBegin.back() + count[hh]);
-  std::vector<int32_t> ids(ni);
-  {
-    std::vector<int> cursor(h->levelBegin.begin(), h->levelBegin.end());
-    for (size_t i = 0; i < ni; i++) ids[cursor[topo.height[i] - 1]++] = (int32_t)i;
-  }
-  CREATE_TRY(h->levelIds.upload(ids.data(), ids.size()));
   // ---- optional region kd-tree: validate, order by height for the refit, upload ----
   for (int k = 0; k < 3; k++) { h->kdLo[k] = INFINITY; h->kdHi[k] = -INFINITY; }
   for (uint64_t r = 0; r < scene->numRegions; r++)
@@ -654,7 +672,7 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   h->sc.domain = h->domain.p;
   for (int f = 0; f < EXA_MAX_CHANNELS; f++) h->sc.channelOffset[f] = f < scene->numFields ? scene->channelOffset[f] : 0;
   h->sc.numRegions = (uint32_t)scene->numRegions;
-  h->sc.numInternal = (uint32_t)ni;
+  h->sc.numInternal = 0;                     // set when the LBVH is built (ensureLbvh)
 #undef CREATE_TRY
   *out = h;
   return 0;
