@@ -102,6 +102,7 @@ struct RenderArgs {
   unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
   int32_t           *errorFlag;     // set when a loop guard trips
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
+  uint32_t          *tileCost;      // != null: per launch slot, march iterations of the tile's longest wave (launch-order feedback)
 };
 
 // ---- launchers implemented in exa_kernels.hip ----

@@ -1410,6 +1410,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
   const int px = tx * kTile + inX, py = ty * kTile + inY;
   const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
 
+  unsigned marchIters = 0;
   if (inside) {
     const ExaHipFrameState &fs = a.fs;
     const int frameID = fs.frameID;
@@ -1474,7 +1475,8 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     const float *field0 = a.sc.scalars + a.sc.channelOffset[0];   // wave-uniform
     const float *field = field0;
 
-    for (unsigned iter = 0;; iter++) {
+    unsigned iter = 0;
+    for (;; iter++) {
       if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
       // ---- refill burst: as soon as one lane of the wave has run dry, every lane with a
       //      free queue slot advances its own walk (all lanes of the wave take part) ----
@@ -1573,6 +1575,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       C.count(ST_SAMPLE_EVALS);
     }
 
+    marchIters = iter;
     float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
     if (SURF) bgColor = a.surf[slot];
     float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
@@ -1588,6 +1591,12 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
   }
 
+  if (a.tileCost) {
+    // launch-order feedback: the longest wave of this tile, in march iterations
+    unsigned v = marchIters;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down((int)v, off, 64));
+    if (lane == 0) atomicMax(&a.tileCost[blockIdx.x], v);
+  }
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
   if (STATS) {
     for (int i = 0; i < ST_COUNT; i++) {

@@ -218,6 +218,10 @@ struct ExaHipRenderer {
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
   DevBuf<float4> accum;
   DevBuf<float4> surf;
+  DevBuf<uint32_t> tileCost;            // launch-order feedback, one entry per launch slot
+  std::vector<int32_t> baseMap, curMap; // static launch order (tile_order) / the order in use
+  int feedback = 1;                     // option tile_feedback
+  int costPhase = 0;                    // 1: the next synchronous frame measures tile costs, then the tiles are re-ordered
   DevBuf<uint32_t> surfRnd;
   DevBuf<uint32_t> color;
   DevBuf<int32_t> tileMap;
@@ -320,7 +324,43 @@ struct ExaHipRenderer {
       }
     }
     HIP_TRY(this, tileMap.upload(map.data(), map.size()));
+    HIP_TRY(this, tileCost.alloc(map.size()));
+    baseMap = map; curMap = map;
+    costPhase = 1;
     layoutDirty = false;
+    return 0;
+  }
+
+  // Launch-order feedback.  A frame's critical path is its longest rays (a wave runs until its
+  // slowest lane is done); launched late they drain alone on an empty GPU — worst on a multi-GPU
+  // shard, where a rank holds little more than one GPU-full of waves.  The frame after a change of
+  // view/TF/layout records each tile's longest wave (march iterations); from then on the heaviest
+  // tiles are launched first (coarse cost classes, the static order inside a class so that the
+  // tiles in flight still share bricks).  Pixels do not depend on the launch order.
+  int reorderFromCosts()
+  {
+    costPhase = 0;
+    const size_t n = curMap.size();
+    if (n < 2) return 0;
+    std::vector<uint32_t> cost(n);
+    HIP_TRY(this, hipMemcpy(cost.data(), tileCost.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> costOfTile(size_t(tilesX) * tilesY, 0);
+    uint32_t maxC = 0;
+    for (size_t b = 0; b < n; b++) { costOfTile[curMap[b]] = cost[b]; maxC = std::max(maxC, cost[b]); }
+    const int kClasses = 32;
+    std::vector<std::vector<int32_t>> cls(kClasses);
+    for (size_t b = 0; b < n; b++) {
+      const int32_t t = baseMap[b];
+      const int c = kClasses - 1 - int(uint64_t(costOfTile[t]) * kClasses / (uint64_t(maxC) + 1));
+      cls[c].push_back(t);
+    }
+    std::vector<int32_t> order;
+    order.reserve(n);
+    for (int c = 0; c < kClasses; c++) order.insert(order.end(), cls[c].begin(), cls[c].end());
+    if (order != curMap) {
+      HIP_TRY(this, hipMemcpy(tileMap.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
+      curMap.swap(order);
+    }
     return 0;
   }
 
@@ -473,6 +513,7 @@ struct ExaHipRenderer {
     return 0;
   }
 
+  bool measureCosts = false;            // set by renderImpl for synchronous frames
   int launch(uint32_t *dstDevice, bool stats, hipStream_t s)
   {
     if (streamDirty && rebuildStreamlines(s)) return 1;
@@ -494,6 +535,11 @@ struct ExaHipRenderer {
     a.stats = statsBuf.p;
     a.errorFlag = errorFlag.p;
     a.debugPixel = debugPixel;
+    a.tileCost = nullptr;
+    if (feedback && costPhase == 1 && useKd() && measureCosts) {
+      HIP_TRY(this, hipMemsetAsync(tileCost.p, 0, tileCost.n * sizeof(uint32_t), s));
+      a.tileCost = tileCost.p;
+    }
     a.kdNodes = kdNodes.p;
     a.regionRec = regionRec.p;
     a.kdRoot = kdRoot;
@@ -706,6 +752,12 @@ int exa_hip_set_frame_state(ExaHipRenderer *h, const ExaHipFrameState *fs)
   if (!h->haveFs || std::memcmp(h->fs.xfDomain, fs->xfDomain, sizeof(fs->xfDomain)) != 0
       || h->fs.xfOpacityScale != fs->xfOpacityScale) h->volDirty = true;
   if (!h->haveFs || std::memcmp(h->fs.iso, fs->iso, sizeof(fs->iso)) != 0) h->isoDirty = true;
+  if (h->haveFs) {
+    // anything but the frame id changes which tiles are expensive
+    ExaHipFrameState a = h->fs, b = *fs;
+    a.frameID = b.frameID = 0;
+    if (std::memcmp(&a, &b, sizeof(a)) != 0) h->costPhase = 1;
+  }
   h->fs = *fs;
   h->haveFs = true;
   return 0;
@@ -718,6 +770,7 @@ int exa_hip_set_xf(ExaHipRenderer *h, int32_t chan, const float *rgba128)
   std::memcpy(h->xfHost[chan], rgba128, sizeof(h->xfHost[chan]));
   h->xfDirty = true;
   h->volDirty = true;                      // needVolumeBVHRebuild = true (OptixRenderer.cpp:403)
+  h->costPhase = 1;
   return 0;
 }
 
@@ -821,6 +874,7 @@ int exa_hip_set_params(ExaHipRenderer *h, const ExaHipParams *p)
   if (!(p->dt > 0.f)) { h->fail("exa_hip_set_params: dt must be > 0"); return 1; }
   if (!h->haveParams || h->p.numChannels != p->numChannels || h->p.spaceSkippingEnabled != p->spaceSkippingEnabled)
     h->volDirty = true;
+  if (!h->haveParams || std::memcmp(&h->p, p, sizeof(*p)) != 0) h->costPhase = 1;
   h->p = *p;
   h->haveParams = true;
   return 0;
@@ -840,6 +894,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
 {
   if (!h || !key) return 1;
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
+  if (!std::strcmp(key, "tile_feedback")) { h->feedback = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
@@ -860,10 +915,13 @@ static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, h
   if (h->prepareFrame(s)) return 1;
   uint32_t *dst = dstIsDevice && rgba8 ? rgba8 : h->color.p;
   if (stats) HIP_TRY(h, hipMemsetAsync(h->statsBuf.p, 0, ST_COUNT * sizeof(unsigned long long), s));
+  const bool willSync = !(async && dstIsDevice && !stats);
+  h->measureCosts = willSync && !stats;
   if (h->launch(dst, stats, s)) return 1;
-  if (async && dstIsDevice && !stats) return 0;
+  if (!willSync) return 0;
   HIP_TRY(h, hipEventSynchronize(h->ev1));
   HIP_TRY(h, hipEventElapsedTime(&h->last.kernel_ms, h->ev0, h->ev1));
+  if (h->measureCosts && h->feedback && h->costPhase == 1 && h->useKd() && h->reorderFromCosts()) return 1;
   const size_t px = (size_t)exa_hip_output_pixels(h);
   if (!dstIsDevice && rgba8) HIP_TRY(h, hipMemcpy(rgba8, h->color.p, px * sizeof(uint32_t), hipMemcpyDeviceToHost));
   int32_t flag = 0;

@@ -189,6 +189,25 @@ def test_state_changes_between_frames():
     R.close()
 
 
+@pytest.mark.parametrize("world", [1, 3])
+def test_launch_order_feedback_does_not_change_pixels(world):
+    """the first frame after a state change records tile costs, later frames launch the heaviest tiles
+    first (option tile_feedback): same pixels before and after, and with the feedback switched off"""
+    case = Case(_amr(), W=200, H=136, grad=1)
+    out = {}
+    for fb in (1, 0):
+        R = case.hip_renderer()
+        R.setOption("tile_feedback", fb)
+        R.setShard(world - 1, world)
+        R.updateFrameID(0)
+        frames = [(R.render().copy(), R.readAccum().copy()) for _ in range(3)]
+        for rgba, acc in frames[1:]:
+            assert np.array_equal(rgba, frames[0][0]) and np.array_equal(acc.view(np.uint32), frames[0][1].view(np.uint32))
+        out[fb] = frames[0]
+        R.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+
+
 def test_progressive_accumulation_16_frames():
     case = Case(scenes.example("ex4"), W=64, H=48, grad=1, fast_math=0)
     o = case.run_oracle(frames=16)
