@@ -238,7 +238,10 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * (default), 5/6/7 Z-order dealt to the XCDs in chunks of 16/64/256 tiles; "accel" 0 = LBVH with restart per segment,
  * 1 = region kd-tree walked front to back (default when the scene carries one); "tile_feedback" 1 (default) = after a
  * change of view / TF / layout the next synchronous frame records every tile's longest ray and later frames launch
- * the heaviest tiles first (a frame's critical path is its longest rays), 0 = keep the static order.
+ * the heaviest tiles first (a frame's critical path is its longest rays), 0 = keep the static order; "wide_march" 1
+ * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes
+ * per ray — consecutive samples evaluated side by side, composited in order, bit-identical pixels — 0 = never,
+ * 2 / 4 = every tile with that many lanes (tests).
  * One knob moves results within the stated float tolerance: "fast_math" 1 (default)
  * evaluates the opacity correction powf as exp2(dt*log2(x)) on the hardware
  * transcendental units (~2 ulp), 0 uses the library powf (<1 ulp). */

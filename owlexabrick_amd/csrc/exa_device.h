@@ -102,6 +102,7 @@ struct RenderArgs {
   unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
   int32_t           *errorFlag;     // set when a loop guard trips
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
+  const int32_t     *wideTileMap;   // wide march: launch slot / L -> global tile id
   uint32_t          *tileCost;      // != null: per launch slot, march iterations of the tile's longest wave (launch-order feedback)
 };
 
@@ -113,7 +114,9 @@ hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, 
 // refit one height class of internal nodes: box of each child = union below it
 hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
                        const uint8_t *active, hipStream_t s);
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool iso, bool stats, hipStream_t s);
+hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s);
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, bool stats, hipStream_t s);
+hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
 hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
 // computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel

@@ -367,12 +367,11 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
   return true;
 }
 
-// exabrick.cu:988-1016 integrateVolume
+// the sample's colour after gradient shading and its opacity after the correction; actual_dt != 0
 template <bool FAST, bool STATS>
-__device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
-                                                float cellValue, V3 gradient, int finestLevelCellWidth, int channel)
+__device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, float actual_dt, float cellValue, V3 gradient,
+                                              int finestLevelCellWidth, int channel)
 {
-  if (actual_dt == 0.f) return;
   Color4 sample = lookupXF<FAST>(C.xfLds, C.a->fs, cellValue, channel);
   if (fsqrt<FAST>(dot(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
@@ -384,11 +383,27 @@ __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, C
   // correctly rounded powf (CUDA's own powf is specified to 4 ulp), x==0 -> 0, x==1 -> 1.
   if (FAST) sample.w = 1.f - __builtin_amdgcn_exp2f(actual_dt * __builtin_amdgcn_logf(1.f - sample.w));
   else      sample.w = 1.f - powf(1.f - sample.w, actual_dt);
+  return sample;
+}
+
+// front-to-back "over" (exabrick.cu:1012-1015)
+__device__ __forceinline__ void compositeSample(Color4 &pixelColor, const Color4 &sample)
+{
   const float k = (1.f - pixelColor.w) * sample.w;
   pixelColor.x += k * sample.x;
   pixelColor.y += k * sample.y;
   pixelColor.z += k * sample.z;
   pixelColor.w += k * 1.f;
+}
+
+// exabrick.cu:988-1016 integrateVolume
+template <bool FAST, bool STATS>
+__device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
+                                                float cellValue, V3 gradient, int finestLevelCellWidth, int channel)
+{
+  if (actual_dt == 0.f) return;
+  const Color4 sample = shadeSample<FAST>(C, ray, actual_dt, cellValue, gradient, finestLevelCellWidth, channel);
+  compositeSample(pixelColor, sample);
 }
 
 #define EXA_TERMINATION_THRESHOLD 0.98f
@@ -1607,19 +1622,280 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
   }
 }
 
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool iso, bool stats, hipStream_t s)
+// ------------------------------------------------------------------------
+// Wide march: L lanes per ray.  A frame's critical path is its longest rays (one lane marches one
+// ray, sample after sample: thousands of dependent iterations of ~2.5 us when the GPU is emptying),
+// which bounds a multi-GPU shard long before throughput does.  Everything that is expensive about a
+// sample — basis reconstruction, TF lookup, shading, opacity correction — does not depend on the
+// colour accumulated so far; only the "over" operator does.  So the L lanes of a ray evaluate L
+// consecutive samples of the segment at once and then composite them in order (every lane does the
+// same ten operations on the same values, so all copies of the pixel stay identical and no lane has
+// to be told about an early termination).  Same samples, same arithmetic, same order as the one-lane
+// march: the pixels are bit-identical.  Lane 0 of a ray owns the kd walk and the segment queue.
+// Used for the tiles the launch-order feedback marks as critical (exa_module: reorderFromCosts);
+// single primary channel only.
+// ------------------------------------------------------------------------
+template <bool GRAD, bool FAST, bool SURF, int L>
+__global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const RenderArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *xfLds = reinterpret_cast<float4 *>(smem);
+  unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
+  int *stackRef = reinterpret_cast<int *>(sp0);
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
+  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
+  __syncthreads();
+
+  Ctx<false> C;
+  C.a = &a;
+  C.xfLds = xfLds;
+  C.stack = stackRef + threadIdx.x;
+  C.guardTripped = false;
+
+  // L workgroups per 16x16 tile; a wave marches 64/L rays
+  const int tile = a.wideTileMap[blockIdx.x / L];
+  const int part = blockIdx.x % L;
+  const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+  const int lane = threadIdx.x & 63, sub = lane & (L - 1), lead = lane & ~(L - 1);
+  const bool leader = sub == 0;
+  const int r = part * (kTilePixels / L) + (threadIdx.x >> 6) * (64 / L) + lane / L;     // ray of the tile
+  const int inX = (((r >> 6) & 1) << 3) + (r & 7), inY = ((r >> 7) << 3) + ((r >> 3) & 7);   // 8x8 block order, as the one-lane kernel
+  const int px = tx * kTile + inX, py = ty * kTile + inY;
+  const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
+
+  if (inside) {
+    const ExaHipFrameState &fs = a.fs;
+    const int frameID = fs.frameID;
+    Lcg rnd;
+    rnd.init((uint32_t)(frameID * a.W * a.H) + (uint32_t)px, (uint32_t)py);      // :1591-1592
+    const float sx = float(px) + rnd.next();
+    const float sy = float(py) + rnd.next();
+    Ray ray;
+    ray.org = mk(fs.cam_pos);
+    ray.dir = normalize((mk(fs.cam_dir00) + sx * mk(fs.cam_dirDu)) + sy * mk(fs.cam_dirDv));
+    ray.tmin = 1e-6f; ray.tmax = 1e8f;
+    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
+                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+    float surface_t_hit = ray.tmax;
+    if (SURF) {
+      surface_t_hit = a.surf[slot].w;
+      rnd.state = a.surfRnd[slot];
+    }
+    const float interleavedSamplingOffset = rnd.next();                           // :1655
+    ray.tmax = surface_t_hit;                                                     // :1657-1659
+    if (fs.clipBox.enabled) {
+      float c0, c1;
+      boxTest(ray, mk(fs.clipBox.lo), mk(fs.clipBox.hi), c0, c1);
+      ray.tmin = c0; ray.tmax = c1;
+    }
+    surface_t_hit = ray.tmax;
+    ray.org = xfmPoint(fs, ray.org);                                              // :1664-1668
+    ray.dir = xfmVector(fs, ray.dir);
+    const float dt_scale = length(ray.dir);
+    ray.dir = normalize(ray.dir);
+    ray.tmin = dt_scale * ray.tmin;
+    ray.tmax = surface_t_hit * dt_scale;
+
+    Color4 pixelColor; pixelColor.x = pixelColor.y = pixelColor.z = pixelColor.w = 0.f;
+
+    KdWalk w;
+    w.pk.v = 0;
+    w.tn = w.tf = w.tEnd = 0.f;
+    w.ref = EXA_KD_DONE;
+    if (leader) {
+      Ray whole = ray; whole.tmin = -INFINITY; whole.tmax = INFINITY;
+      float r0, r1;
+      const bool hit = boxTest(whole, mk(a.kdLo), mk(a.kdHi), r0, r1);
+      w.tn = fmaxf(r0, ray.tmin);
+      w.tf = fminf(r1, ray.tmax);
+      w.tEnd = w.tf;
+      w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
+    }
+    float walkTmin = ray.tmin;
+
+    bool haveSeg = false, newStep = false, needHdr = false, mine = false;
+    int listBegin = 0, listSize = 0;
+    float flcw = 1.f, dtSeg = 0.f;
+    float t1 = 0.f, tiBase = 0.f, tlBase = 0.f;        // t_i of the step's first sample, t_next of the sample before it
+    float t_sample = 0.f, actual_dt = 0.f;
+    int child = 0;
+    int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 0, 0);
+    Basis B;
+    B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+    const float *field0 = a.sc.scalars + a.sc.channelOffset[0];
+
+    for (unsigned iter = 0;; iter++) {
+      if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
+      // ---- refill burst, leaders only ----
+      if (__any(leader && !haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
+        for (;;) {
+          const bool want = leader && w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
+          if (!__any(want)) break;
+          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f);
+        }
+      }
+      if (!haveSeg) {
+        // ---- next segment: the leader pops, the ray's lanes share it ----
+        int region = -1;
+        float t0 = 0.f, tEnd = 0.f;
+        if (leader) {
+          const int qc = w.pk.get(PK_QCOUNT);
+          if (qc > 0) {
+            const int qh = w.pk.get(PK_QHEAD);
+            region = qRegion[qh * kKdBlock];
+            t0 = qT[(2 * qh) * kKdBlock];
+            tEnd = qT[(2 * qh + 1) * kKdBlock];
+            w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
+            w.pk.set(PK_QCOUNT, qc - 1);
+          }
+        }
+        region = __shfl(region, lead, 64);
+        if (region < 0) break;                                                     // walk finished: ray done
+        t0 = __shfl(t0, lead, 64);
+        t1 = __shfl(tEnd, lead, 64);
+        {
+          const RegionInfo ri = a.sc.regionInfo[region];
+          listBegin = ri.listBegin; listSize = ri.listSize;
+          flcw = ri.finestLevelCellWidth;
+        }
+        dtSeg = a.p.dt * flcw;
+        tiBase = firstSampleT(t0, dtSeg, interleavedSamplingOffset);               // :1141-1144
+        tlBase = t0;
+        haveSeg = true; newStep = true; needHdr = true;
+      }
+      if (newStep) {
+        // ---- this lane's sample of the step: sample `sub` after the step's first one (:1158-1166) ----
+        float ti = tiBase, tl = tlBase, myTn = 0.f, myTl = 0.f;
+        bool ex = true;
+        mine = false;
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+          const float tn = fminf(ti, t1);
+          if (s == sub) { myTn = tn; myTl = tl; mine = ex; }
+          ex = ex && tn < t1;                     // the segment ends with the first sample that reaches t1 (:1182)
+          tl = tn;
+          ti = ti + dtSeg;
+        }
+        t_sample = 0.5f * (fminf(t1, myTn) + myTl);
+        actual_dt = myTn - myTl;
+        newStep = false;
+      }
+
+      // ---- one brick visit of this lane's sample ----
+      if (mine) {
+        if (listSize > 1 || needHdr) {
+          const unsigned at = 2u * (unsigned)(listBegin + child);
+          hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
+        }
+        addBasisFast<GRAD, false>(C, B, hb0, hb1, field0, ray.org + t_sample * ray.dir);   // :1166
+      }
+      needHdr = false;
+      child++;
+      if (child < listSize) continue;
+
+      // ---- this lane's sample: value, gradient, colour and corrected opacity (:800-806, :910-927, :988-1011) ----
+      Color4 smp; smp.x = smp.y = smp.z = smp.w = 0.f;
+      int contributes = 0;
+      if (mine && B.sumW > 1e-20f && actual_dt != 0.f) {
+        const float cellValue = fdiv<FAST>(B.sumWV, B.sumW);
+        V3 grad = mk(0.f, 0.f, 0.f);
+        if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
+                            B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
+                            B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
+        smp = shadeSample<FAST>(C, ray, actual_dt, cellValue, grad, (int)flcw, 0);
+        contributes = 1;
+      }
+      B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+      child = 0;
+
+      // ---- composite the step's samples in order; every lane of the ray keeps the same pixel ----
+      bool rayDone = false, segDone = false;
+      {
+        float ti = tiBase, tl = tlBase;
+#pragma unroll
+        for (int s = 0; s < L; s++) {
+          Color4 o;
+          o.x = __shfl(smp.x, lead + s, 64); o.y = __shfl(smp.y, lead + s, 64);
+          o.z = __shfl(smp.z, lead + s, 64); o.w = __shfl(smp.w, lead + s, 64);
+          const int oc = __shfl(contributes, lead + s, 64);
+          if (!rayDone && !segDone) {
+            const float tn = fminf(ti, t1);
+            if (oc) compositeSample(pixelColor, o);
+            if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) rayDone = true;         // :1180
+            else if (tn >= t1) segDone = true;                                     // :1182
+            tl = tn;
+            ti = ti + dtSeg;
+          }
+        }
+        tiBase = ti; tlBase = tl;
+      }
+      if (rayDone) {
+        pixelColor.x = pixelColor.x * pixelColor.w;                                // :1694-1696
+        pixelColor.y = pixelColor.y * pixelColor.w;
+        pixelColor.z = pixelColor.z * pixelColor.w;
+        pixelColor.w = 1.f;
+        break;
+      }
+      if (segDone) haveSeg = false;
+      else newStep = true;
+    }
+
+    if (leader) {
+      float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (SURF) bgColor = a.surf[slot];
+      float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
+      float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
+      float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
+      if (frameID > 0) {
+        const float4 acc = a.accum[slot];
+        cr += acc.x; cg += acc.y; cb += acc.z;
+      }
+      a.accum[slot] = make_float4(cr, cg, cb, 1.f);
+      const float div = frameID + 1.f;
+      cr = cr / div; cg = cg / div; cb = cb / div;
+      a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+    }
+  }
+  if (C.guardTripped) atomicExch(a.errorFlag, 1);
+}
+
+hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s)
+{
+  if (numTiles <= 0) return hipSuccess;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
+  const dim3 grid(numTiles * lanesPerRay), block(kKdBlock);
+#define EXA_W3(G, F, S) do { if (lanesPerRay == 2) hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, 2>), grid, block, lds, s, a); \
+                             else hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, 4>), grid, block, lds, s, a); } while (0)
+#define EXA_W2(G, F) do { if (surf) EXA_W3(G, F, true); else EXA_W3(G, F, false); } while (0)
+  if (grad) { if (fast) EXA_W2(true, true); else EXA_W2(true, false); }
+  else      { if (fast) EXA_W2(false, true); else EXA_W2(false, false); }
+#undef EXA_W2
+#undef EXA_W3
+  return hipGetLastError();
+}
+
+hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s)
+{
+  if (numBlocks <= 0) return hipSuccess;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
+  const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
+  if (stats) hipLaunchKernelGGL((surfacePrepassKdKernel<true>), grid, block, lds, s, a);
+  else       hipLaunchKernelGGL((surfacePrepassKdKernel<false>), grid, block, lds, s, a);
+  return hipGetLastError();
+}
+
+// the march over a.tileMap[0..numBlocks); `surf`: a surfaces pre-pass has filled a.surf / a.surfRnd
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, bool stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   const bool multi = a.p.numPrimaryChannels > 1;
-  if (iso) {
-    if (stats) hipLaunchKernelGGL((surfacePrepassKdKernel<true>), grid, block, lds, s, a);
-    else       hipLaunchKernelGGL((surfacePrepassKdKernel<false>), grid, block, lds, s, a);
-  }
 #define EXA_LAUNCH(G, F, M, I, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S>), grid, block, lds, s, a)
 #define EXA_PICK2(G, F, M, I) do { if (stats) EXA_LAUNCH(G, F, M, I, true); else EXA_LAUNCH(G, F, M, I, false); } while (0)
-#define EXA_PICK(G, F, M) do { if (iso) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
+#define EXA_PICK(G, F, M) do { if (surf) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
   if (grad) {
     if (fast) { if (multi) EXA_PICK(true, true, true); else EXA_PICK(true, true, false); }
     else      { if (multi) EXA_PICK(true, false, true); else EXA_PICK(true, false, false); }

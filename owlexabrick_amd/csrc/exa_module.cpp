@@ -9,6 +9,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <utility>
@@ -222,6 +223,13 @@ struct ExaHipRenderer {
   std::vector<int32_t> baseMap, curMap; // static launch order (tile_order) / the order in use
   int feedback = 1;                     // option tile_feedback
   int costPhase = 0;                    // 1: the next synchronous frame measures tile costs, then the tiles are re-ordered
+  // wide march (L lanes per ray) for the tiles on the frame's critical path
+  int wideMode = 1;                     // option wide_march: 0 off, 1 by cost, 2 / 4 every tile with that many lanes (tests)
+  int numSimdWaves = 256 * 4 * 6;       // waves the device holds at the march kernel's occupancy
+  DevBuf<int32_t> normalMap, wideMap;   // one-lane tiles in launch order; wide tiles, the 4-lane ones first
+  int nNormal = 0, nWide4 = 0, nWide2 = 0;
+  hipStream_t side4 = nullptr, side2 = nullptr, sideN = nullptr;
+  hipEvent_t evFork = nullptr, evJoin4 = nullptr, evJoin2 = nullptr, evJoinN = nullptr;
   DevBuf<uint32_t> surfRnd;
   DevBuf<uint32_t> color;
   DevBuf<int32_t> tileMap;
@@ -327,6 +335,8 @@ struct ExaHipRenderer {
     HIP_TRY(this, tileCost.alloc(map.size()));
     baseMap = map; curMap = map;
     costPhase = 1;
+    nNormal = nWide4 = nWide2 = 0;
+    if (assignWide(nullptr)) return 1;
     layoutDirty = false;
     return 0;
   }
@@ -354,6 +364,14 @@ struct ExaHipRenderer {
       const int c = kClasses - 1 - int(uint64_t(costOfTile[t]) * kClasses / (uint64_t(maxC) + 1));
       cls[c].push_back(t);
     }
+    if (std::getenv("EXA_HIP_VERBOSE")) {
+      uint64_t sum = 0;
+      for (size_t b = 0; b < n; b++) sum += cost[b];
+      std::fprintf(stderr, "[exa_hip] tile costs: %zu tiles, max %u iterations, sum %llu, per class (heaviest first):", n, maxC,
+                   (unsigned long long)sum);
+      for (int c = 0; c < kClasses; c++) std::fprintf(stderr, " %zu", cls[c].size());
+      std::fprintf(stderr, "\n");
+    }
     std::vector<int32_t> order;
     order.reserve(n);
     for (int c = 0; c < kClasses; c++) order.insert(order.end(), cls[c].begin(), cls[c].end());
@@ -361,6 +379,48 @@ struct ExaHipRenderer {
       HIP_TRY(this, hipMemcpy(tileMap.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
       curMap.swap(order);
     }
+    return assignWide(&costOfTile);
+  }
+
+  // Which tiles march with 2 or 4 lanes per ray.  In units of one wave's march iterations on an idle
+  // GPU: a tile's critical path is cost / speedup(L); the time the GPU needs for everything else is
+  // the work (4 waves per tile, x L / speedup(L) for a wide tile) over the waves it holds, at the pace
+  // of a loaded GPU.  Heaviest tiles first, each gets the smallest L that brings its path below the
+  // fill time; on one GPU nothing qualifies, on a shard of 8 the few hundred longest tiles do.
+  int assignWide(const std::vector<uint32_t> *costOfTile)
+  {
+    const size_t n = curMap.size();
+    std::vector<int32_t> normal, w4, w2;
+    if (wideMode == 2 || wideMode == 4) {
+      (wideMode == 4 ? w4 : w2) = curMap;
+    } else if (wideMode == 1 && costOfTile) {
+      // measured on C4 / MI355X (tests/gpu_shard_scaling.py): a critical tile finishes 1.33x / 1.64x
+      // sooner with 2 / 4 lanes per ray and costs 1.47x / 2.19x the work; a loaded GPU steps a wave 1.3x slower
+      const double kSpeed2 = 1.33, kSpeed4 = 1.64, kWork2 = 1.47, kWork4 = 2.19, kLoaded = 1.3;
+      double fill = 0;
+      for (size_t b = 0; b < n; b++) fill += 4.0 * (*costOfTile)[curMap[b]];
+      fill *= kLoaded / numSimdWaves;
+      // curMap is ordered by descending cost class; inside a class the decision only depends on the tile's own cost
+      for (size_t b = 0; b < n; b++) {
+        const int32_t t = curMap[b];
+        const double c = (*costOfTile)[t];
+        int L = 1;
+        if (c > fill) L = (c / kSpeed2 > fill) ? 4 : 2;
+        if (L == 1) { normal.push_back(t); continue; }
+        fill += 4.0 * c * ((L == 4 ? kWork4 : kWork2) - 1.0) * kLoaded / numSimdWaves;
+        (L == 4 ? w4 : w2).push_back(t);
+      }
+    } else {
+      normal = curMap;
+    }
+    if (wideMode != 2 && wideMode != 4 && w4.empty() && w2.empty()) { nNormal = (int)n; nWide4 = nWide2 = 0; return 0; }
+    std::vector<int32_t> wide(w4);
+    wide.insert(wide.end(), w2.begin(), w2.end());
+    HIP_TRY(this, normalMap.upload(normal.data(), normal.size()));
+    HIP_TRY(this, wideMap.upload(wide.data(), wide.size()));
+    nNormal = (int)normal.size(); nWide4 = (int)w4.size(); nWide2 = (int)w2.size();
+    if (std::getenv("EXA_HIP_VERBOSE"))
+      std::fprintf(stderr, "[exa_hip] wide march: %d tiles x4 lanes, %d x2, %d one lane per ray\n", nWide4, nWide2, nNormal);
     return 0;
   }
 
@@ -560,7 +620,40 @@ struct ExaHipRenderer {
       a.surf = surf.p; a.surfRnd = surfRnd.p;
     }
     HIP_TRY(this, hipEventRecord(ev0, s));
-    if (useKd()) HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfacesEnabled(), stats, s));
+    if (useKd()) {
+      const bool surfOn = surfacesEnabled();
+      if (surfOn) HIP_TRY(this, launchSurfacePrepassKd(a, numBlocks, stats, s));
+      const bool wide = !stats && !a.tileCost && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
+      if (!wide) {
+        HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats, s));
+      } else {
+        // the critical tiles on side streams so that they start together with the rest of the frame
+        HIP_TRY(this, hipEventRecord(evFork, s));
+        RenderArgs aw = a;
+        if (nWide4) {
+          HIP_TRY(this, hipStreamWaitEvent(side4, evFork, 0));
+          aw.wideTileMap = wideMap.p;
+          HIP_TRY(this, launchRenderKdWide(aw, nWide4, 4, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side4));
+          HIP_TRY(this, hipEventRecord(evJoin4, side4));
+        }
+        if (nWide2) {
+          HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
+          aw.wideTileMap = wideMap.p + nWide4;
+          HIP_TRY(this, launchRenderKdWide(aw, nWide2, 2, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side2));
+          HIP_TRY(this, hipEventRecord(evJoin2, side2));
+        }
+        // the rest of the frame on a stream of its own as well: launched on the caller's stream it would not
+        // overlap the side streams when that stream is the (synchronising) null stream
+        RenderArgs an = a;
+        an.tileMap = normalMap.p;
+        HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
+        HIP_TRY(this, launchRenderKd(an, nNormal, p.gradientShadingDVR != 0, fastMath != 0, surfOn, false, sideN));
+        HIP_TRY(this, hipEventRecord(evJoinN, sideN));
+        if (nWide4) HIP_TRY(this, hipStreamWaitEvent(s, evJoin4, 0));
+        if (nWide2) HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
+        HIP_TRY(this, hipStreamWaitEvent(s, evJoinN, 0));
+      }
+    }
     else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, surfacesEnabled(), stats, s));
     last.node_bytes = useKd() ? sizeof(KdNodeDev) : sizeof(BvhNode);
     HIP_TRY(this, hipEventRecord(ev1, s));
@@ -708,6 +801,18 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   CREATE_TRY(hipEventCreate(&h->ev0));
   CREATE_TRY(hipEventCreate(&h->ev1));
   CREATE_TRY(hipEventCreate(&h->ev2));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evJoin4, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evJoin2, hipEventDisableTiming));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->side4, hipStreamNonBlocking));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->sideN, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evJoinN, hipEventDisableTiming));
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+      h->numSimdWaves = prop.multiProcessorCount * 4 * 6;
+  }
 
   h->sc.bricks = h->bricks.p;
   h->sc.leafList = h->leafList.p;
@@ -732,6 +837,13 @@ int exa_hip_destroy(ExaHipRenderer *h)
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   if (h->ev2) (void)hipEventDestroy(h->ev2);
+  if (h->evFork) (void)hipEventDestroy(h->evFork);
+  if (h->evJoin4) (void)hipEventDestroy(h->evJoin4);
+  if (h->evJoin2) (void)hipEventDestroy(h->evJoin2);
+  if (h->side4) (void)hipStreamDestroy(h->side4);
+  if (h->side2) (void)hipStreamDestroy(h->side2);
+  if (h->sideN) (void)hipStreamDestroy(h->sideN);
+  if (h->evJoinN) (void)hipEventDestroy(h->evJoinN);
   delete h;
   return 0;
 }
@@ -895,6 +1007,10 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!h || !key) return 1;
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "tile_feedback")) { h->feedback = value; h->layoutDirty = true; return 0; }
+  if (!std::strcmp(key, "wide_march")) {
+    if (value != 0 && value != 1 && value != 2 && value != 4) { h->fail("exa_hip_set_option: wide_march is 0, 1, 2 or 4"); return 1; }
+    h->wideMode = value; h->layoutDirty = true; return 0;
+  }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }

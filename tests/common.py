@@ -110,6 +110,8 @@ class Case:
             R.setOption("accel", self.accel)
         if self.fast_math is not None:
             R.setOption("fast_math", self.fast_math)
+        for k, v in getattr(self, "options", {}).items():
+            R.setOption(k, v)
         lo, hi = prep.voxel_bounds()
         cam = self.cam(lo, hi)
         if self.xfm is not None:

@@ -189,6 +189,22 @@ def test_state_changes_between_frames():
     R.close()
 
 
+@pytest.mark.parametrize("lanes", [2, 4])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_wide_march_is_bit_identical(name, lanes):
+    """wide_march = 2 / 4 marches every tile with that many lanes per ray (normally only the tiles on a
+    frame's critical path): consecutive samples evaluated side by side, composited in order — the same
+    accumulation buffer bit for bit, over 2 accumulated frames (scenes with several primary channels keep
+    the one-lane march)"""
+    out = {}
+    for mode in (0, lanes):
+        case = CASES[name]()
+        case.options = {"wide_march": mode}
+        out[mode] = case.run_hip(frames=2)
+    assert np.array_equal(out[0][1].view(np.uint32), out[lanes][1].view(np.uint32))
+    assert np.array_equal(out[0][0], out[lanes][0])
+
+
 @pytest.mark.parametrize("world", [1, 3])
 def test_launch_order_feedback_does_not_change_pixels(world):
     """the first frame after a state change records tile costs, later frames launch the heaviest tiles
