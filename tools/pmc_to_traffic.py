@@ -18,5 +18,8 @@ path = os.path.join(root, "profiles", "hbm_traffic.json")
 d = json.load(open(path)) if os.path.exists(path) else {}
 d[key] = (2 * fetch + write) * 1024
 d[key + ":note"] = f"2*FETCH_SIZE({fetch:.6g} KiB)+WRITE_SIZE({write:.6g} KiB), from {os.path.basename(out)}"
+m = re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", blk)
+if m:
+    d[key + ":valu_wave_instructions"] = float(m.group(1))
 json.dump(d, open(path, "w"), indent=1)
 print(path, d[key])
