@@ -39,6 +39,25 @@ def algorithmic_bytes(st, pixels, frame_id=0):
             + pixels * (4 + 16 + (16 if frame_id > 0 else 0)))
 
 
+def effective_cpus():
+    """host cores this process may really use: affinity mask and cgroup quota, not the machine's thread count
+    (a one-GPU box of the pool shows 256 hardware threads but grants a share of 16)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    if os.environ.get("EXA_BENCH_CPU_THREADS"):
+        n = int(os.environ["EXA_BENCH_CPU_THREADS"])
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,7 +108,7 @@ def main():
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where collectives operate
 
     W = H = args.size
-    host_threads = max(1, (os.cpu_count() or 8) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
+    host_threads = max(2, effective_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))))
 
     # ---------------- scene: generate, prepare, upload ----------------
     t0 = time.time()
@@ -269,7 +288,7 @@ def main():
             fs = po.FrameState()
             harness.fill_frame_state(fs, cam, [scene.value_range], xfOpacityScale=1.0, frameID=0)
             P = po.Params(0.5, 1, 0, 0 if args.no_grad else 1, 1, 1, 1)
-            cores = os.cpu_count() or 1
+            cores = effective_cpus()
             # calibrate on a 64x64 centre window (after a warm-up that spins the threads up),
             # then size the crop for ~cpu-seconds of work
             c0 = W // 2
