@@ -1654,6 +1654,8 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   C.stack = stackRef + threadIdx.x;
   C.guardTripped = false;
 
+  // these waves are the frame's critical path: let them issue ahead of the one-lane march they share SIMDs with
+  __builtin_amdgcn_s_setprio(3);
   // L workgroups per 16x16 tile; a wave marches 64/L rays
   const int tile = a.wideTileMap[blockIdx.x / L];
   const int part = blockIdx.x % L;
