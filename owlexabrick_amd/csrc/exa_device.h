@@ -103,7 +103,7 @@ struct RenderArgs {
   int32_t           *errorFlag;     // set when a loop guard trips
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
   const int32_t     *wideTileMap;   // wide march: launch slot / L -> global tile id
-  uint32_t          *tileCost;      // != null: per launch slot, march iterations of the tile's longest wave (launch-order feedback)
+  uint32_t          *tileCost;      // != null: per tile id, brick visits of the tile's longest ray (launch-order feedback)
 };
 
 // ---- launchers implemented in exa_kernels.hip ----

@@ -1607,10 +1607,10 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
   }
 
   if (a.tileCost) {
-    // launch-order feedback: the longest wave of this tile, in march iterations
+    // launch-order feedback: the longest ray of this tile, in brick visits (= march iterations of its lane)
     unsigned v = marchIters;
     for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down((int)v, off, 64));
-    if (lane == 0) atomicMax(&a.tileCost[blockIdx.x], v);
+    if (lane == 0) atomicMax(&a.tileCost[tile], v);
   }
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
   if (STATS) {
@@ -1667,6 +1667,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   const int px = tx * kTile + inX, py = ty * kTile + inY;
   const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
 
+  unsigned myVisits = 0;
   if (inside) {
     const ExaHipFrameState &fs = a.fs;
     const int frameID = fs.frameID;
@@ -1792,6 +1793,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
           hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
         }
         addBasisFast<GRAD, false>(C, B, hb0, hb1, field0, ray.org + t_sample * ray.dir);   // :1166
+        myVisits++;
       }
       needHdr = false;
       child++;
@@ -1859,6 +1861,13 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       cr = cr / div; cg = cg / div; cb = cb / div;
       a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
     }
+  }
+  if (a.tileCost) {
+    // launch-order feedback in the one-lane kernel's unit: brick visits of the tile's longest ray
+    unsigned v = myVisits;
+    for (int off = 1; off < L; off <<= 1) v += (unsigned)__shfl_xor((int)v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down((int)v, off, 64));
+    if (lane == 0) atomicMax(&a.tileCost[tile], v);
   }
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
 }

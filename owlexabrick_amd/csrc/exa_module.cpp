@@ -149,7 +149,19 @@ struct DevBuf {
     if (e != hipSuccess || count == 0) return e;
     return hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice);
   }
-  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; }
+  // like upload, but keeps the allocation when it is large enough (per-frame tables)
+  hipError_t refill(const T *src, size_t count)
+  {
+    if (count > cap || !p) {
+      hipError_t e = alloc(std::max(count, size_t(1)));
+      if (e != hipSuccess) return e;
+      cap = std::max(count, size_t(1));
+    }
+    n = count;
+    return count ? hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice) : hipSuccess;
+  }
+  size_t cap = 0;
+  void release() { if (p) (void)hipFree(p); p = nullptr; n = 0; cap = 0; }
   ~DevBuf() { release(); }
 };
 
@@ -219,7 +231,7 @@ struct ExaHipRenderer {
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
   DevBuf<float4> accum;
   DevBuf<float4> surf;
-  DevBuf<uint32_t> tileCost;            // launch-order feedback, one entry per launch slot
+  DevBuf<uint32_t> tileCost;            // launch-order feedback, one entry per tile of the image
   std::vector<int32_t> baseMap, curMap; // static launch order (tile_order) / the order in use
   int feedback = 1;                     // option tile_feedback
   int costPhase = 0;                    // 1: the next synchronous frame measures tile costs, then the tiles are re-ordered
@@ -332,7 +344,7 @@ struct ExaHipRenderer {
       }
     }
     HIP_TRY(this, tileMap.upload(map.data(), map.size()));
-    HIP_TRY(this, tileCost.alloc(map.size()));
+    HIP_TRY(this, tileCost.alloc(size_t(tilesX) * tilesY));
     baseMap = map; curMap = map;
     costPhase = 1;
     nNormal = nWide4 = nWide2 = 0;
@@ -352,11 +364,10 @@ struct ExaHipRenderer {
     costPhase = 0;
     const size_t n = curMap.size();
     if (n < 2) return 0;
-    std::vector<uint32_t> cost(n);
-    HIP_TRY(this, hipMemcpy(cost.data(), tileCost.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     std::vector<uint32_t> costOfTile(size_t(tilesX) * tilesY, 0);
+    HIP_TRY(this, hipMemcpy(costOfTile.data(), tileCost.p, costOfTile.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     uint32_t maxC = 0;
-    for (size_t b = 0; b < n; b++) { costOfTile[curMap[b]] = cost[b]; maxC = std::max(maxC, cost[b]); }
+    for (size_t b = 0; b < n; b++) maxC = std::max(maxC, costOfTile[curMap[b]]);
     const int kClasses = 32;
     std::vector<std::vector<int32_t>> cls(kClasses);
     for (size_t b = 0; b < n; b++) {
@@ -366,7 +377,7 @@ struct ExaHipRenderer {
     }
     if (std::getenv("EXA_HIP_VERBOSE")) {
       uint64_t sum = 0;
-      for (size_t b = 0; b < n; b++) sum += cost[b];
+      for (size_t b = 0; b < n; b++) sum += costOfTile[curMap[b]];
       std::fprintf(stderr, "[exa_hip] tile costs: %zu tiles, max %u iterations, sum %llu, per class (heaviest first):", n, maxC,
                    (unsigned long long)sum);
       for (int c = 0; c < kClasses; c++) std::fprintf(stderr, " %zu", cls[c].size());
@@ -416,8 +427,8 @@ struct ExaHipRenderer {
     if (wideMode != 2 && wideMode != 4 && w4.empty() && w2.empty()) { nNormal = (int)n; nWide4 = nWide2 = 0; return 0; }
     std::vector<int32_t> wide(w4);
     wide.insert(wide.end(), w2.begin(), w2.end());
-    HIP_TRY(this, normalMap.upload(normal.data(), normal.size()));
-    HIP_TRY(this, wideMap.upload(wide.data(), wide.size()));
+    HIP_TRY(this, normalMap.refill(normal.data(), normal.size()));
+    HIP_TRY(this, wideMap.refill(wide.data(), wide.size()));
     nNormal = (int)normal.size(); nWide4 = (int)w4.size(); nWide2 = (int)w2.size();
     if (std::getenv("EXA_HIP_VERBOSE"))
       std::fprintf(stderr, "[exa_hip] wide march: %d tiles x4 lanes, %d x2, %d one lane per ray\n", nWide4, nWide2, nNormal);
@@ -623,7 +634,7 @@ struct ExaHipRenderer {
     if (useKd()) {
       const bool surfOn = surfacesEnabled();
       if (surfOn) HIP_TRY(this, launchSurfacePrepassKd(a, numBlocks, stats, s));
-      const bool wide = !stats && !a.tileCost && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
+      const bool wide = !stats && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
       if (!wide) {
         HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats, s));
       } else {

@@ -214,14 +214,24 @@ def test_launch_order_feedback_does_not_change_pixels(world):
     for fb in (1, 0):
         R = case.hip_renderer()
         R.setOption("tile_feedback", fb)
+        R.setOption("wide_march", 1 if fb else 0)
         R.setShard(world - 1, world)
         R.updateFrameID(0)
         frames = [(R.render().copy(), R.readAccum().copy()) for _ in range(3)]
         for rgba, acc in frames[1:]:
             assert np.array_equal(rgba, frames[0][0]) and np.array_equal(acc.view(np.uint32), frames[0][1].view(np.uint32))
         out[fb] = frames[0]
+        # a moving camera re-measures every frame (with whatever mix of one-lane and wide tiles is active)
+        cams = [harness.camera([-30.0 - 4 * i, 70.0 + 3 * i, 90.0], [24, 22, 14], [0, 1, 0], 50.0, 200, 136) for i in range(3)]
+        moved = []
+        for cam in cams:
+            R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
+            moved.append((R.render().copy(), R.readAccum().copy()))
+        out[(fb, "moved")] = moved
         R.close()
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    for a, b in zip(out[(0, "moved")], out[(1, "moved")]):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
 
 
 def test_progressive_accumulation_16_frames():
