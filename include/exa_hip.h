@@ -121,6 +121,8 @@ typedef struct ExaHipStats {
   uint64_t pixels;        /* pixels rendered by this handle (its tile shard)       */
   uint64_t diag[9];       /* kd kernel diagnostics: {waves,lanes} x {brick visit, sample epilogue,
                              kd node step, leaf accept}, then kd-interval/slab-test mismatches */
+  uint64_t phase_cycles[5]; /* kd kernel: shader-clock cycles of its waves, summed, by phase: brick visit, sample
+                             epilogue, kd walk, segment pop, other (ray set-up, output) */
   float    kernel_ms;     /* hipEvent time of the last render launch               */
   float    rebuild_ms;    /* hipEvent time of the last activity+refit pass         */
 } ExaHipStats;
@@ -241,7 +243,8 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * the heaviest tiles first (a frame's critical path is its longest rays), 0 = keep the static order; "wide_march" 1
  * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes
  * per ray — consecutive samples evaluated side by side, composited in order, bit-identical pixels — 0 = never,
- * 2 / 4 = every tile with that many lanes (tests).
+ * 2 / 4 = every tile with that many lanes (tests); "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
+ * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change.
  * One knob moves results within the stated float tolerance: "fast_math" 1 (default)
  * evaluates the opacity correction powf as exp2(dt*log2(x)) on the hardware
  * transcendental units (~2 ulp), 0 uses the library powf (<1 ulp). */

@@ -68,7 +68,10 @@ enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CO
                 // wave-level diagnostics of the instrumented v2 kernel: executions of a phase by a wave,
                 // and lanes active in them (lane utilisation = lanes / (64 * waves))
                 ST_W_BRICK, ST_L_BRICK, ST_W_FINAL, ST_L_FINAL, ST_W_NODE, ST_L_NODE, ST_W_LEAF, ST_L_LEAF,
-                ST_KD_MISMATCH, ST_COUNT };
+                ST_KD_MISMATCH,
+                // shader-clock cycles of the waves by phase (sum over waves): brick visit, sample epilogue, kd walk,
+                // segment pop, everything else (ray set-up, output)
+                ST_T_BRICK, ST_T_FINAL, ST_T_WALK, ST_T_SEG, ST_T_OTHER, ST_COUNT };
 
 struct RenderArgs {
   DeviceScene        sc;
@@ -115,7 +118,7 @@ hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, 
 hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
                        const uint8_t *active, hipStream_t s);
 hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s);
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, bool stats, hipStream_t s);
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats /*0, 1 counters, 2 phase times*/, hipStream_t s);
 hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
 hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);

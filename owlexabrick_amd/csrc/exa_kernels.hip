@@ -62,19 +62,34 @@ template <bool FAST> __device__ __forceinline__ float fsqrt(float a) { return FA
 struct Ray { V3 org, dir; float tmin, tmax; };
 struct Color4 { float x, y, z, w; };
 
-// per-thread view of the kernel state
-template <bool STATS>
+// per-thread view of the kernel state.  STATS: 0 = the shipped kernel, 1 = work counters (sample for sample the
+// oracle's), 2 = wave time by phase only (the shipped code plus a clock read at every phase change)
+template <int STATS>
 struct Ctx {
   const RenderArgs *a;
   const float4 *xfLds;         // TF tables staged in LDS
   int *stack;                  // this thread's LBVH stack column in LDS (stride 256)
   unsigned long long st[ST_COUNT];
   bool guardTripped;
-  __device__ __forceinline__ void count(int slot, unsigned long long n = 1) { if (STATS) st[slot] += n; }
+  __device__ __forceinline__ void count(int slot, unsigned long long n = 1) { if (STATS == 1) st[slot] += n; }
+  // wave time by phase (instrumented variant): the cycles since the wave's previous mark go to the phase that
+  // mark opened; one lane of the active set keeps the books, the mark itself lives in LDS (per wave)
+  unsigned long long *lapMark;   // this wave's record in LDS: [0] time of the last mark, [1] its phase, [2..6] cycles per phase
+  __device__ __forceinline__ void lap(int phaseSlot)
+  {
+    if (STATS == 2) {
+      const unsigned long long now = clock64();
+      const unsigned long long m = __ballot(1);
+      if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) {
+        lapMark[2 + lapMark[1]] += now - lapMark[0];
+        lapMark[0] = now; lapMark[1] = (unsigned long long)(phaseSlot - ST_T_BRICK);
+      }
+    }
+  }
   // one count per wave execution (first active lane) + one per active lane
   __device__ __forceinline__ void phase(int waveSlot)
   {
-    if (STATS) {
+    if (STATS == 1) {
       const unsigned long long m = __ballot(1);
       if ((threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) st[waveSlot]++;
       st[waveSlot + 1]++;
@@ -146,7 +161,7 @@ __device__ __forceinline__ bool boxTest(const Ray &ray, V3 lo, V3 hi, float &t0,
 // ------------------------------------------------------------------------
 struct RegionHit { int leafID; float t0, t1; };
 
-template <bool STATS>
+template <int STATS>
 __device__ __forceinline__ RegionHit traceRegion(Ctx<STATS> &C, const BvhNode *nodes, const Ray &ray)
 {
   RegionHit best; best.leafID = -1; best.t0 = INFINITY; best.t1 = 0.f;
@@ -199,7 +214,7 @@ __device__ __forceinline__ RegionHit traceRegion(Ctx<STATS> &C, const BvhNode *n
 // ------------------------------------------------------------------------
 struct Basis { float sumWV, sumW; V3 sumD, sumDC; };
 
-template <bool DERIV, bool STATS>
+template <bool DERIV, int STATS>
 __device__ __forceinline__ void addBasisFunctions(Ctx<STATS> &C, Basis &B, const int4 b0, const int4 b1,
                                                   const float *__restrict__ field, V3 pos)
 {
@@ -247,7 +262,7 @@ __device__ __forceinline__ void addBasisFunctions(Ctx<STATS> &C, Basis &B, const
     }                                                                                        \
     B.sumW = v_ ? B.sumW + w_ : B.sumW;                                                      \
     B.sumWV = v_ ? B.sumWV + w_ * (S) : B.sumWV;                                             \
-    if (STATS && v_) C.st[ST_CORNER_LOADS]++;                                                \
+    if (STATS == 1 && v_) C.st[ST_CORNER_LOADS]++;                                                \
   }
   // corner order of the reference: z-lo{y-lo{x-lo,x-hi}, y-hi{..}}, z-hi{..}
   EXA_CORNER(vlz && vly && vlx, s000, nz, ny, nx, -, -, -)   // :644-658
@@ -270,7 +285,7 @@ __device__ __forceinline__ Pair loadPair(const float *__restrict__ p) { return *
 // leaves a sum unchanged (the sums start at +0 and can never become -0), so the
 // accumulators see bit-identical values.  The speculative read of an out-of-brick corner
 // is clamped onto a cell that an in-brick corner of the same sample reads as well.
-template <bool DERIV, bool STATS>
+template <bool DERIV, int STATS>
 __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4 b0, const int4 b1,
                                              const float *__restrict__ field, V3 pos)
 {
@@ -303,7 +318,7 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const float s001 = lFirst ? pLH.a : pLH.b, s101 = hFirst ? pLH.a : pLH.b;
   const float s011 = lFirst ? pHH.a : pHH.b, s111 = hFirst ? pHH.a : pHH.b;
   C.count(ST_BRICK_VISITS);
-  if (STATS) C.st[ST_CORNER_LOADS] += (unsigned)((int(vlx) + int(vhx)) * (int(vly) + int(vhy)) * (int(vlz) + int(vhz)));
+  if (STATS == 1) C.st[ST_CORNER_LOADS] += (unsigned)((int(vlx) + int(vhx)) * (int(vly) + int(vhy)) * (int(vlz) + int(vhz)));
   // masked per-axis weights: (1-frac) for the low cell, frac for the high cell
   const float wxl = vlx ? 1.f - fx : 0.f, wxh = vhx ? fx : 0.f;
   const float wyl = vly ? 1.f - fy : 0.f, wyh = vhy ? fy : 0.f;
@@ -343,7 +358,7 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
 }
 
 // exabrick.cu:781-806 samplePoint / :883-928 samplePointWithDerivative
-template <bool DERIV, bool STATS>
+template <bool DERIV, int STATS>
 __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &derivatives,
                                             const RegionInfo &ri, V3 pos, int channel)
 {
@@ -368,7 +383,7 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
 }
 
 // the sample's colour after gradient shading and its opacity after the correction; actual_dt != 0
-template <bool FAST, bool STATS>
+template <bool FAST, int STATS>
 __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, float actual_dt, float cellValue, V3 gradient,
                                               int finestLevelCellWidth, int channel)
 {
@@ -397,7 +412,7 @@ __device__ __forceinline__ void compositeSample(Color4 &pixelColor, const Color4
 }
 
 // exabrick.cu:988-1016 integrateVolume
-template <bool FAST, bool STATS>
+template <bool FAST, int STATS>
 __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
                                                 float cellValue, V3 gradient, int finestLevelCellWidth, int channel)
 {
@@ -420,7 +435,7 @@ __device__ __forceinline__ float firstSampleT(float t0, float dt, float off)
 }
 
 // exabrick.cu:1116-1185 integrateBrick<GRADIENT_SHADING>
-template <bool GRAD, bool STATS>
+template <bool GRAD, int STATS>
 __device__ __forceinline__ void integrateBrick(Ctx<STATS> &C, Color4 &pixelColor, float off, const Ray &ray,
                                                const RegionInfo &ri, float t0, float t1, int numChannels)
 {
@@ -455,7 +470,7 @@ __device__ __forceinline__ void integrateBrick(Ctx<STATS> &C, Color4 &pixelColor
 struct IsoResult { Color4 pixelColor; float t_hit; V3 gradient; };
 
 // exabrick.cu:1018-1114 IsoSurfaceIntegrationFunction::operator()
-template <bool STATS>
+template <int STATS>
 __device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, const Ray &ray, IsoResult &result,
                         float t_sample, float cellValueIn, const RegionInfo &ri, int channel)
 {
@@ -549,7 +564,7 @@ __device__ __forceinline__ float intersectRayTriangle(const Ray &ray, V3 v1, V3 
 // traceContourRay (:1345-1406).  findRegion(pos) is the degenerate trace of samplePointWithInfRay
 // (:818-830: origin pos, direction (1,1,1), [0, 2e-10]) on whichever structure the kernel walks;
 // the reference reads region[-1] when it misses, here the sample is skipped (value 0).
-template <bool STATS, class FindRegion>
+template <int STATS, class FindRegion>
 __device__ SurfaceHit traceContourRay(Ctx<STATS> &C, const Ray &ray, V3 normal, float offset, int channel, FindRegion findRegion)
 {
   SurfaceHit prd;
@@ -608,7 +623,7 @@ __device__ SurfaceHit traceContourRay(Ctx<STATS> &C, const Ray &ray, V3 normal, 
 // closest-hit program (:420-433).  OptiX's built-in triangle test is replaced by the reference's own
 // intersectRayTriangle (:1316-1343); closest t in (tmin,tmax), lowest triangle index on a tie.
 // ------------------------------------------------------------------------
-template <bool STATS>
+template <int STATS>
 __device__ void traceMeshes(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
 {
   const RenderArgs &a = *C.a;
@@ -694,7 +709,7 @@ __device__ __forceinline__ bool intersectRoundedCone(V3 pa, V3 pb, float ra, flo
   return false;
 }
 
-template <bool STATS>
+template <int STATS>
 __device__ void traceStreamlines(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
 {
   const RenderArgs &a = *C.a;
@@ -741,7 +756,7 @@ __device__ void traceStreamlines(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
 }
 
 // exabrick.cu:1187-1256 isoIntegrateBrick
-template <bool STATS>
+template <int STATS>
 __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellValue, IsoResult &ir, float off,
                                   const Ray &ray, const RegionInfo &ri, float t0, float t1, int numChannels)
 {
@@ -762,7 +777,7 @@ __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellV
       // reads; its sample matters solely through the `break` below once the segment already holds an
       // opaque hit.  Outside that case it is skipped (the instrumented variant keeps the reference's
       // full count of evaluations).
-      if (!STATS && !((isoChannelMask >> c) & 1u) && ir.pixelColor.w < EXA_TERMINATION_THRESHOLD) continue;
+      if (STATS != 1 && !((isoChannelMask >> c) & 1u) && ir.pixelColor.w < EXA_TERMINATION_THRESHOLD) continue;
       float cellValue = 0.f;
       V3 grad = mk(0.f, 0.f, 0.f);
       bool doIntegrate;
@@ -779,7 +794,7 @@ __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellV
 }
 
 // exabrick.cu:1408-1460 traceIsoRay (LBVH: one closest-region search per segment)
-template <bool STATS>
+template <int STATS>
 __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
 {
   const ExaHipFrameState &fs = C.a->fs;
@@ -820,7 +835,7 @@ __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
 }
 
 // exabrick.cu:1475-1529 traceSurfaces: contour planes, then implicit iso-surfaces
-template <bool STATS>
+template <int STATS>
 __device__ __forceinline__ void traceSurfaces(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd, bool withContourPlanes)
 {
   prd.primID = -1;
@@ -851,7 +866,7 @@ __device__ __forceinline__ void traceSurfaces(Ctx<STATS> &C, const Ray &ray, Sur
 // ------------------------------------------------------------------------
 // exabrick.cu:1576-1720 renderFrame
 // ------------------------------------------------------------------------
-template <bool GRAD, bool ISO, bool STATS>
+template <bool GRAD, bool ISO, int STATS>
 __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1047,7 +1062,7 @@ struct KdWalk {
 };
 #define EXA_KD_DONE (EXA_KD_EMPTY + 1)
 
-template <bool STATS>
+template <int STATS>
 __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs &a, float *stackF)
 {
   const int count = w.pk.get(PK_SCOUNT);
@@ -1078,7 +1093,7 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs
 // one step of the walk: pop / descend one level / accept-or-skip a leaf
 // ISOWALK: the iso march multiplies ray.tmax by dt_scale before every trace (exabrick.cu:1434), so the
 // walk is not clamped at the root; the current tmax clamps t1 at the leaf and ends the walk.
-template <bool ISOWALK, bool STATS>
+template <bool ISOWALK, int STATS>
 __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a,
                                        float *stackF, int *qRegion, float *qT, const Ray &ray, const int which,
                                        float &walkTmax, const float dtScale)
@@ -1098,7 +1113,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     const float t0 = fmaxf(walkTmin, w.tn);
     const float t1 = ISOWALK ? fminf(walkTmax, w.tf) : w.tf;
     const bool hit = t0 < t1;
-    if (STATS) {
+    if (STATS == 1) {
       const float4 *rp = reinterpret_cast<const float4 *>(a.regionRec + region);
       const float4 r0 = rp[0], r1 = rp[1];
       Ray rr = ray; rr.tmin = walkTmin;
@@ -1173,7 +1188,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
 // exabrick.cu:1408-1460 traceIsoRay on the kd walk (iso activity bits): segments come out of the
 // ordered walk, one lane at a time refills its own queue here (the iso pre-pass is not the
 // headline path), the march is isoIntegrateBrick.
-template <bool STATS>
+template <int STATS>
 __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *stackF, int *qRegion, float *qT)
 {
   const RenderArgs &a = *C.a;
@@ -1239,7 +1254,7 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
 
 // samplePointWithInfRay's degenerate trace on the kd walk: first accepted leaf of the ray
 // (pos, (1,1,1), [0, 2e-10]) under the volume activity bits
-template <bool STATS>
+template <int STATS>
 __device__ int kdFindRegion(Ctx<STATS> &C, V3 pos, float *stackF, int *qRegion, float *qT)
 {
   const RenderArgs &a = *C.a;
@@ -1261,7 +1276,7 @@ __device__ int kdFindRegion(Ctx<STATS> &C, V3 pos, float *stackF, int *qRegion, 
   return w.pk.get(PK_QCOUNT) ? qRegion[w.pk.get(PK_QHEAD) * kKdBlock] : -1;
 }
 
-template <bool STATS>
+template <int STATS>
 __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd, bool withContourPlanes,
                                                 float *stackF, int *qRegion, float *qT)
 {
@@ -1294,7 +1309,7 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
 // to it through a[].surf / surfRnd: the generic surface code needs ~130 VGPRs, the march 80, and one
 // fused kernel would run the march at half its occupancy.
 // ------------------------------------------------------------------------
-template <bool STATS>
+template <int STATS>
 __global__ __launch_bounds__(kKdBlock, 3) void surfacePrepassKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1395,7 +1410,7 @@ __global__ __launch_bounds__(kKdBlock, 3) void surfacePrepassKdKernel(const Rend
   }
 }
 
-template <bool GRAD, bool FAST, bool MULTI, bool SURF, bool STATS>
+template <bool GRAD, bool FAST, bool MULTI, bool SURF, int STATS>
 __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1414,6 +1429,14 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
   C.stack = stackRef + threadIdx.x;
   C.guardTripped = false;
   if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
+  __shared__ unsigned long long lapMarks[STATS == 2 ? 8 * (kKdBlock / 64) : 1];
+  if (STATS == 2) {
+    C.lapMark = lapMarks + 8 * (threadIdx.x >> 6);
+    if ((threadIdx.x & 63) == 0) {
+      C.lapMark[0] = clock64(); C.lapMark[1] = ST_T_OTHER - ST_T_BRICK;
+      for (int i = 2; i < 7; i++) C.lapMark[i] = 0;
+    }
+  }
 
   // a workgroup is kKdBlock/64 waves; each wave renders one 8x8 block of a 16x16 tile
   const int wavesPerBlock = kKdBlock / 64;
@@ -1496,6 +1519,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       // ---- refill burst: as soon as one lane of the wave has run dry, every lane with a
       //      free queue slot advances its own walk (all lanes of the wave take part) ----
       if (__any(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
+        C.lap(ST_T_WALK);
         for (;;) {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
           if (!__any(want)) break;
@@ -1504,6 +1528,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       }
       if (!haveSeg) {
         // ---- next segment from this lane's queue ----
+        C.lap(ST_T_SEG);
         const int qc = w.pk.get(PK_QCOUNT);
         if (qc == 0) break;                                                        // walk finished: ray done
         const int qh = w.pk.get(PK_QHEAD);
@@ -1534,6 +1559,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       }
 
       // ---- one brick visit ----
+      C.lap(ST_T_BRICK);
       C.phase(ST_W_BRICK);
       // brick records are stored along the leaf list (no id indirection); a one-brick region keeps the
       // record it loaded at the start of the segment
@@ -1547,6 +1573,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       if (child < listSize) continue;
 
       // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
+      C.lap(ST_T_FINAL);
       C.phase(ST_W_FINAL);
       if (B.sumW > 1e-20f) {
         C.count(ST_SAMPLES);
@@ -1590,6 +1617,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       C.count(ST_SAMPLE_EVALS);
     }
 
+    C.lap(ST_T_OTHER);
     marchIters = iter;
     float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
     if (SURF) bgColor = a.surf[slot];
@@ -1613,7 +1641,10 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     if (lane == 0) atomicMax(&a.tileCost[tile], v);
   }
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
-  if (STATS) {
+  if (STATS == 2) {
+    if (lane < 5 && C.lapMark[2 + lane]) atomicAdd(&a.stats[ST_T_BRICK + lane], C.lapMark[2 + lane]);
+  }
+  if (STATS == 1) {
     for (int i = 0; i < ST_COUNT; i++) {
       unsigned long long v = inside ? C.st[i] : 0ull;
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -1892,20 +1923,20 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
   if (numBlocks <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
-  if (stats) hipLaunchKernelGGL((surfacePrepassKdKernel<true>), grid, block, lds, s, a);
-  else       hipLaunchKernelGGL((surfacePrepassKdKernel<false>), grid, block, lds, s, a);
+  if (stats) hipLaunchKernelGGL((surfacePrepassKdKernel<1>), grid, block, lds, s, a);
+  else       hipLaunchKernelGGL((surfacePrepassKdKernel<0>), grid, block, lds, s, a);
   return hipGetLastError();
 }
 
 // the march over a.tileMap[0..numBlocks); `surf`: a surfaces pre-pass has filled a.surf / a.surfRnd
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, bool stats, hipStream_t s)
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   const bool multi = a.p.numPrimaryChannels > 1;
 #define EXA_LAUNCH(G, F, M, I, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S>), grid, block, lds, s, a)
-#define EXA_PICK2(G, F, M, I) do { if (stats) EXA_LAUNCH(G, F, M, I, true); else EXA_LAUNCH(G, F, M, I, false); } while (0)
+#define EXA_PICK2(G, F, M, I) do { if (stats == 1) EXA_LAUNCH(G, F, M, I, 1); else if (stats == 2) EXA_LAUNCH(G, F, M, I, 2); else EXA_LAUNCH(G, F, M, I, 0); } while (0)
 #define EXA_PICK(G, F, M) do { if (surf) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
   if (grad) {
     if (fast) { if (multi) EXA_PICK(true, true, true); else EXA_PICK(true, true, false); }

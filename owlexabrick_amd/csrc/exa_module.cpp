@@ -234,6 +234,7 @@ struct ExaHipRenderer {
   DevBuf<uint32_t> tileCost;            // launch-order feedback, one entry per tile of the image
   std::vector<int32_t> baseMap, curMap; // static launch order (tile_order) / the order in use
   int feedback = 1;                     // option tile_feedback
+  int statsMode = 1;                    // option stats_mode: what exa_hip_render_stats collects (1 work counters, 2 wave time by phase)
   int costPhase = 0;                    // 1: the next synchronous frame measures tile costs, then the tiles are re-ordered
   // wide march (L lanes per ray) for the tiles on the frame's critical path
   int wideMode = 1;                     // option wide_march: 0 off, 1 by cost, 2 / 4 every tile with that many lanes (tests)
@@ -636,7 +637,7 @@ struct ExaHipRenderer {
       if (surfOn) HIP_TRY(this, launchSurfacePrepassKd(a, numBlocks, stats, s));
       const bool wide = !stats && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
       if (!wide) {
-        HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats, s));
+        HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats ? statsMode : 0, s));
       } else {
         // the critical tiles on side streams so that they start together with the rest of the frame
         HIP_TRY(this, hipEventRecord(evFork, s));
@@ -1022,6 +1023,10 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     if (value != 0 && value != 1 && value != 2 && value != 4) { h->fail("exa_hip_set_option: wide_march is 0, 1, 2 or 4"); return 1; }
     h->wideMode = value; h->layoutDirty = true; return 0;
   }
+  if (!std::strcmp(key, "stats_mode")) {
+    if (value != 1 && value != 2) { h->fail("exa_hip_set_option: stats_mode is 1 or 2"); return 1; }
+    h->statsMode = value; return 0;
+  }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
@@ -1065,6 +1070,7 @@ static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, h
     h->last.brick_visits = c[ST_BRICK_VISITS]; h->last.corner_loads = c[ST_CORNER_LOADS];
     h->last.iso_segments = c[ST_ISO_SEGMENTS]; h->last.iso_evals = c[ST_ISO_EVALS]; h->last.nodes_visited = c[ST_NODES];
     for (int i = 0; i < 9; i++) h->last.diag[i] = c[ST_W_BRICK + i];
+    for (int i = 0; i < 5; i++) h->last.phase_cycles[i] = c[ST_T_BRICK + i];
   }
   h->last.pixels = px;
   return 0;

@@ -11,11 +11,19 @@ R = case.hip_renderer()
 _, st = R.renderStats()
 d = st["diag"]
 names = ["brick", "final", "node", "leaf"]
-print({k: v for k, v in st.items() if k != "diag"})
+print({k: v for k, v in st.items() if k not in ("diag", "phase_cycles")})
 for i, n in enumerate(names):
     w, l = d[2 * i], d[2 * i + 1]
     print(f"{n:6s} wave-execs {w:.4g} lanes {l:.4g} util {l / max(1, 64 * w):.3f}")
 print("kd mismatches", d[8])
+R.setOption("stats_mode", 2)
+_, st2 = R.renderStats()
+R.setOption("stats_mode", 1)
+print("timing variant kernel_ms", st2["kernel_ms"])
+pc = st2["phase_cycles"]
+tot = float(sum(pc)) or 1.0
+for n, c in zip(["brick visit", "sample epilogue", "kd walk", "segment pop", "other"], pc):
+    print(f"wave cycles in {n:16s} {c:.4g}  {100 * c / tot:.1f} %")
 for k in range(3):
     R.render()
 print("kernel_ms", R.stats()["kernel_ms"])
