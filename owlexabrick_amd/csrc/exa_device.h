@@ -78,6 +78,10 @@ struct RenderArgs {
   const BvhNode     *volNodes;
   const BvhNode     *isoNodes;
   const KdNodeDev   *kdNodes;       // region kd-tree (NULL: LBVH only)
+  const KdNodeDev   *kdMarchNodes;  // the tree the volume march walks: kdNodes, or its copy whose leaf references are
+                                    // the packed region records {listBegin | listSize-1 | level} (leafBeginBits != 0)
+  int32_t            kdMarchRoot;
+  uint32_t           leafBeginBits, leafSizeBits;
   const RegionRec   *regionRec;
   int32_t            kdRoot;
   float              kdLo[3], kdHi[3];   // box of the kd root = union of all brick domains
@@ -121,7 +125,7 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
 hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats /*0, 1 counters, 2 phase times*/, hipStream_t s);
 hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
-hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
+hipError_t launchKdRefit(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
 // computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel
 hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,

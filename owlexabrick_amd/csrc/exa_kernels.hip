@@ -1063,7 +1063,7 @@ struct KdWalk {
 #define EXA_KD_DONE (EXA_KD_EMPTY + 1)
 
 template <int STATS>
-__device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs &a, float *stackF)
+__device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, float *stackF)
 {
   const int count = w.pk.get(PK_SCOUNT);
   if (count > 0) {
@@ -1075,7 +1075,7 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs
     w.tn = stackF[(2 * head) * kKdBlock];
     w.tf = stackF[(2 * head + 1) * kKdBlock];
   } else if (w.pk.get(PK_DROPPED) && w.tf < w.tEnd) {
-    w.ref = a.kdRoot;                  // short-stack restart: everything before tf is done
+    w.ref = root;                      // short-stack restart: everything before tf is done
     w.tn = w.tf;
     w.tf = w.tEnd;
     w.pk.set(PK_DROPPED, 0);
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const RenderArgs
 template <bool ISOWALK, int STATS>
 __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a,
                                        float *stackF, int *qRegion, float *qT, const Ray &ray, const int which,
-                                       float &walkTmax, const float dtScale)
+                                       float &walkTmax, const float dtScale, const KdNodeDev *nodes, const int root)
 {
   // A call runs up to three stages in a row — leaf, pop, node — so that a lane that has just
   // queued a leaf also takes the next node in the same call (the wave executes all three
@@ -1135,10 +1135,10 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     }
     w.ref = EXA_KD_EMPTY;
   }
-  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop(C, w, a, stackF);
+  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop(C, w, root, stackF);
   // the popped subtree gets its own look at tmin / tmax in the next call
   if (w.ref < 0 || !(w.tf > walkTmin) || (ISOWALK && !(w.tn < walkTmax))) return;
-  const int4 n = *reinterpret_cast<const int4 *>(a.kdNodes + w.ref);
+  const int4 n = *reinterpret_cast<const int4 *>(nodes + w.ref);
   C.count(ST_NODES);
   C.phase(ST_W_NODE);
   const float split = __int_as_float(n.x);
@@ -1155,7 +1155,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     // (boxTest turns lo==o / hi==o into a miss, exabrick.cu:201-208 with NaN-ignoring min/max)
     if (o < split && (bits & 1)) w.ref = n.z;
     else if (o > split && (bits & 2)) w.ref = n.w;
-    else kdPop(C, w, a, stackF);
+    else kdPop(C, w, root, stackF);
     return;
   }
   const float ts = (split - o) / d;                         // same expression as the slab test
@@ -1163,9 +1163,9 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
   const int nearRef = nearIsLeft ? n.z : n.w, farRef = nearIsLeft ? n.w : n.z;
   const bool nearAct = (bits & (nearIsLeft ? 1 : 2)) != 0, farAct = (bits & (nearIsLeft ? 2 : 1)) != 0;
   if (ts >= w.tf) {                                          // plane behind the interval: near side only
-    if (nearAct) w.ref = nearRef; else kdPop(C, w, a, stackF);
+    if (nearAct) w.ref = nearRef; else kdPop(C, w, root, stackF);
   } else if (ts <= w.tn) {                                   // plane before the interval: far side only
-    if (farAct) w.ref = farRef; else kdPop(C, w, a, stackF);
+    if (farAct) w.ref = farRef; else kdPop(C, w, root, stackF);
   } else if (nearAct) {
     if (farAct) {                                            // push far [ts,tf], go near [tn,ts]
       const int head = w.pk.get(PK_SHEAD), count = w.pk.get(PK_SCOUNT);
@@ -1181,7 +1181,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     w.ref = farRef;
     w.tn = ts;
   } else {
-    kdPop(C, w, a, stackF);
+    kdPop(C, w, root, stackF);
   }
 }
 
@@ -1224,7 +1224,7 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
         if (g >= (1 << 24)) { C.guardTripped = true; w.ref = EXA_KD_DONE; break; }
         const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
         if (!__any(want)) break;
-        if (want) kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale);
+        if (want) kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale, a.kdNodes, a.kdRoot);
       }
     }
     const int qc = w.pk.get(PK_QCOUNT);
@@ -1271,7 +1271,7 @@ __device__ int kdFindRegion(Ctx<STATS> &C, V3 pos, float *stackF, int *qRegion, 
   float walkTmin = ray.tmin;
   for (int g = 0; w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE; g++) {
     if (g >= (1 << 24)) { C.guardTripped = true; break; }
-    kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f);
+    kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdNodes, a.kdRoot);
   }
   return w.pk.get(PK_QCOUNT) ? qRegion[w.pk.get(PK_QHEAD) * kKdBlock] : -1;
 }
@@ -1496,7 +1496,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       w.tn = fmaxf(r0, ray.tmin);
       w.tf = fminf(r1, ray.tmax);
       w.tEnd = w.tf;
-      w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
+      w.ref = (hit && w.tn < w.tf) ? a.kdMarchRoot : EXA_KD_DONE;
     }
 
     float walkTmin = ray.tmin;
@@ -1523,7 +1523,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         for (;;) {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
           if (!__any(want)) break;
-          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f);
+          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
         }
       }
       if (!haveSeg) {
@@ -1537,7 +1537,14 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         t1 = qT[(2 * qh + 1) * kKdBlock];
         w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
         w.pk.set(PK_QCOUNT, qc - 1);
-        {
+        if (a.leafBeginBits) {
+          // the leaf reference of the march tree is the region's record itself: no load between the queue and
+          // the first brick record
+          const unsigned d = (unsigned)region;
+          listBegin = (int)(d & ((1u << a.leafBeginBits) - 1u));
+          listSize = (int)((d >> a.leafBeginBits) & ((1u << a.leafSizeBits) - 1u)) + 1;
+          flcw = __int_as_float((127 + (int)(d >> (a.leafBeginBits + a.leafSizeBits))) << 23);     // 2^level
+        } else {
           const RegionInfo ri = a.sc.regionInfo[region];
           listBegin = ri.listBegin; listSize = ri.listSize;
           flcw = ri.finestLevelCellWidth;
@@ -1745,7 +1752,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       w.tn = fmaxf(r0, ray.tmin);
       w.tf = fminf(r1, ray.tmax);
       w.tEnd = w.tf;
-      w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
+      w.ref = (hit && w.tn < w.tf) ? a.kdMarchRoot : EXA_KD_DONE;
     }
     float walkTmin = ray.tmin;
 
@@ -1767,7 +1774,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
         for (;;) {
           const bool want = leader && w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
           if (!__any(want)) break;
-          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f);
+          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
         }
       }
       if (!haveSeg) {
@@ -1789,7 +1796,14 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
         if (region < 0) break;                                                     // walk finished: ray done
         t0 = __shfl(t0, lead, 64);
         t1 = __shfl(tEnd, lead, 64);
-        {
+        if (a.leafBeginBits) {
+          // the leaf reference of the march tree is the region's record itself: no load between the queue and
+          // the first brick record
+          const unsigned d = (unsigned)region;
+          listBegin = (int)(d & ((1u << a.leafBeginBits) - 1u));
+          listSize = (int)((d >> a.leafBeginBits) & ((1u << a.leafSizeBits) - 1u)) + 1;
+          flcw = __int_as_float((127 + (int)(d >> (a.leafBeginBits + a.leafSizeBits))) << 23);     // 2^level
+        } else {
           const RegionInfo ri = a.sc.regionInfo[region];
           listBegin = ri.listBegin; listSize = ri.listSize;
           flcw = ri.finestLevelCellWidth;
@@ -1952,7 +1966,7 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
 }
 
 // kd activity bits, one height class per launch (children before parents)
-__global__ __launch_bounds__(256) void kdRefitKernel(KdNodeDev *nodes, const int32_t *nodeIds, int count,
+__global__ __launch_bounds__(256) void kdRefitKernel(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count,
                                                      const uint8_t *active, int which)
 {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1966,13 +1980,15 @@ __global__ __launch_bounds__(256) void kdRefitKernel(KdNodeDev *nodes, const int
     return ((nodes[ref].word >> sh) & 3u) ? 1u : 0u;
   };
   const uint32_t bits = act(n.left) | (act(n.right) << 1);
-  nodes[id].word = (n.word & ~(3u << sh)) | (bits << sh);
+  const uint32_t word = (n.word & ~(3u << sh)) | (bits << sh);
+  nodes[id].word = word;
+  if (marchNodes) marchNodes[id].word = word;      // same tree, leaf references replaced by region records
 }
 
-hipError_t launchKdRefit(KdNodeDev *nodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s)
+hipError_t launchKdRefit(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s)
 {
   if (count <= 0) return hipSuccess;
-  hipLaunchKernelGGL(kdRefitKernel, dim3((count + 255) / 256), dim3(256), 0, s, nodes, nodeIds, count, active, which);
+  hipLaunchKernelGGL(kdRefitKernel, dim3((count + 255) / 256), dim3(256), 0, s, nodes, marchNodes, nodeIds, count, active, which);
   return hipGetLastError();
 }
 

@@ -185,6 +185,9 @@ struct ExaHipRenderer {
 
   // region kd-tree (optional; exact front-to-back walk)
   DevBuf<KdNodeDev> kdNodes;
+  DevBuf<KdNodeDev> kdMarchNodes;       // copy of kdNodes whose leaf references are packed region records (may be empty)
+  int32_t kdMarchRoot = 0;
+  uint32_t leafBeginBits = 0, leafSizeBits = 0;
   DevBuf<RegionRec> regionRec;
   DevBuf<int32_t> kdLevelIds;
   std::vector<int> kdLevelBegin;
@@ -439,7 +442,7 @@ struct ExaHipRenderer {
   int kdRefit(const uint8_t *active, int which, hipStream_t s)
   {
     for (size_t h = 0; h + 1 < kdLevelBegin.size(); h++)
-      HIP_TRY(this, launchKdRefit(kdNodes.p, kdLevelIds.p + kdLevelBegin[h], kdLevelBegin[h + 1] - kdLevelBegin[h],
+      HIP_TRY(this, launchKdRefit(kdNodes.p, kdMarchNodes.p, kdLevelIds.p + kdLevelBegin[h], kdLevelBegin[h + 1] - kdLevelBegin[h],
                                   active, which, s));
     return 0;
   }
@@ -613,6 +616,12 @@ struct ExaHipRenderer {
       a.tileCost = tileCost.p;
     }
     a.kdNodes = kdNodes.p;
+    // the instrumented counters re-check every leaf against its region record, so they walk the tree with region ids
+    const bool packed = kdMarchNodes.p != nullptr && !(stats && statsMode == 1);
+    a.kdMarchNodes = packed ? kdMarchNodes.p : kdNodes.p;
+    a.kdMarchRoot = packed ? kdMarchRoot : kdRoot;
+    a.leafBeginBits = packed ? leafBeginBits : 0;
+    a.leafSizeBits = packed ? leafSizeBits : 0;
     a.regionRec = regionRec.p;
     a.kdRoot = kdRoot;
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
@@ -798,6 +807,48 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
       q.listBegin = R.leafListBegin; q.listSize = R.leafListSize; q.pad0 = q.pad1 = 0;
     }
     CREATE_TRY(h->kdNodes.upload(kd.data(), kd.size()));
+    // March tree: the same nodes with every leaf reference replaced by the region's record
+    // {listBegin | listSize-1 | log2(finestLevelCellWidth)}, when the scene's ranges fit 31 bits, so that a segment
+    // start needs no region-info load (one dependent HBM/L2 round trip less per segment).
+    {
+      auto bitsFor = [](uint64_t maxValue) { uint32_t b = 0; while (b < 63 && (1ull << b) <= maxValue) b++; return b; };
+      uint64_t maxSize = 1; int maxLevel = 0; bool pow2 = true;
+      for (uint64_t r = 0; r < scene->numRegions; r++) {
+        const ExaBrickRegion &R = scene->regions[r];
+        maxSize = std::max<uint64_t>(maxSize, (uint64_t)R.leafListSize);
+        int lv = 0;
+        while (lv < 31 && float(1 << lv) < R.finestLevelCellWidth) lv++;
+        if (float(1 << lv) != R.finestLevelCellWidth) pow2 = false;
+        maxLevel = std::max(maxLevel, lv);
+      }
+      const uint32_t bb = std::max(1u, bitsFor(scene->leafListSize ? scene->leafListSize - 1 : 0));
+      const uint32_t sb = bitsFor(maxSize - 1), lb = bitsFor((uint64_t)maxLevel);
+      if (pow2 && bb + sb + lb <= 31) {
+        auto pack = [&](int32_t ref) -> int32_t {
+          if (ref >= 0 || ref == EXA_KD_EMPTY) return ref;
+          const ExaBrickRegion &R = scene->regions[~ref];
+          int lv = 0;
+          while (float(1 << lv) < R.finestLevelCellWidth) lv++;
+          const uint32_t d = uint32_t(R.leafListBegin) | (uint32_t(R.leafListSize - 1) << bb) | (uint32_t(lv) << (bb + sb));
+          return ~int32_t(d);
+        };
+        std::vector<KdNodeDev> mk(kd);
+        bool clash = false;
+        for (auto &n : mk) {
+          n.left = pack(n.left); n.right = pack(n.right);
+          // ~d must not collide with the walk's two sentinels (INT32_MIN, INT32_MIN + 1)
+          clash = clash || (n.left < 0 && n.left != EXA_KD_EMPTY && n.left <= INT32_MIN + 1) || (n.right < 0 && n.right != EXA_KD_EMPTY && n.right <= INT32_MIN + 1);
+        }
+        const int32_t root = pack(scene->kdRoot);
+        clash = clash || (root < 0 && root <= INT32_MIN + 1);
+        if (!clash) {
+          if (mk.empty()) mk.resize(1);              // single-region scene: the root is the leaf
+          CREATE_TRY(h->kdMarchNodes.upload(mk.data(), mk.size()));
+          h->kdMarchRoot = root;
+          h->leafBeginBits = bb; h->leafSizeBits = sb;
+        }
+      }
+    }
     CREATE_TRY(h->kdLevelIds.upload(kids.data(), kids.size()));
     CREATE_TRY(h->regionRec.upload(rec.data(), rec.size()));
     h->kdRoot = scene->kdRoot;
