@@ -69,7 +69,7 @@ def main():
     ap.add_argument("--config", default="c4_exajet")
     ap.add_argument("--no-grad", action="store_true", help="gradient shading off (reference default is on)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=45.0)
     ap.add_argument("--tile-order", type=int, default=int(os.environ.get("EXA_TILE_ORDER", "4")))
     ap.add_argument("--accel", type=int, default=int(os.environ.get("EXA_ACCEL", "1")),
                     help="1 = region kd-tree walked front to back (default), 0 = LBVH restarted per segment")

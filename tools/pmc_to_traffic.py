@@ -10,7 +10,7 @@ import sys
 
 out, key = sys.argv[1], sys.argv[2]
 txt = open(os.path.join(out, "summary.txt")).read()
-blk = [b for b in txt.split("== ") if b.startswith("void exa::renderFrame") and ", false>" in b.split("\n")[0]][0]
+blk = [b for b in txt.split("== ") if b.startswith("void exa::renderFrame") and (", false>" in b.split("\n")[0] or ", 0>" in b.split("\n")[0])][0]
 fetch = float(re.search(r"FETCH_SIZE\s+([0-9.e+]+)", blk).group(1))
 write = float(re.search(r"WRITE_SIZE\s+([0-9.e+]+)", blk).group(1))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
