@@ -189,6 +189,20 @@ def test_state_changes_between_frames():
     R.close()
 
 
+def test_phase_time_variant_keeps_pixels_and_reports_cycles():
+    """stats_mode 2: the shipped march plus a clock read at every phase change"""
+    case = CASES["amr_grad"]()
+    plain = case.run_hip()
+    R = case.hip_renderer()
+    R.setOption("stats_mode", 2)
+    rgba, st = R.renderStats()
+    acc = R.readAccum()
+    R.close()
+    assert np.array_equal(plain[0], rgba) and np.array_equal(plain[1].view(np.uint32), acc.view(np.uint32))
+    pc = st["phase_cycles"]
+    assert all(c > 0 for c in pc[:4]) and st["samples"] == 0      # times, no work counters
+
+
 @pytest.mark.parametrize("lanes", [2, 4])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_wide_march_is_bit_identical(name, lanes):
