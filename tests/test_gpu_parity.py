@@ -189,6 +189,44 @@ def test_state_changes_between_frames():
     R.close()
 
 
+@pytest.mark.parametrize("what", ["1x1", "17x5", "more_ranks_than_tiles", "transparent_tf", "opaque_tf", "camera_inside"])
+def test_scheduling_edge_cases(what):
+    """launch-order feedback and wide march under degenerate frames: same pixels as the static one-lane launch
+    over three frames (measure, reorder, steady state), nothing hangs or faults"""
+    kw, shard = dict(W=96, H=64, grad=1), (0, 1)
+    if what == "1x1":
+        kw.update(W=1, H=1)
+    elif what == "17x5":
+        kw.update(W=17, H=5)
+    elif what == "more_ranks_than_tiles":
+        kw.update(W=40, H=24)               # 3 x 2 tiles
+        shard = (7, 8)                      # this rank owns no tile at all
+    elif what == "transparent_tf":
+        xf = harness.default_xf(); xf[:, 3] = 0.0
+        kw.update(xf=xf)
+    elif what == "opaque_tf":
+        xf = harness.default_xf(); xf[:, 3] = 1.0
+        kw.update(xf=xf)
+    elif what == "camera_inside":
+        kw.update(camera=([20.3, 22.1, 14.2], [30, 20, 10], [0, 1, 0], 80.0))
+    out = {}
+    for sched in (0, 1):
+        case = Case(_amr(), **kw)
+        case.options = {"tile_feedback": sched, "wide_march": sched}
+        R = case.hip_renderer()
+        R.setShard(*shard)
+        R.updateFrameID(0)
+        frames = []
+        for _ in range(3):
+            rgba = R.render()
+            frames.append((np.array(rgba, copy=True), R.readAccum().copy()))
+        R.close()
+        for f in frames[1:]:
+            assert np.array_equal(f[0], frames[0][0]) and np.array_equal(f[1].view(np.uint32), frames[0][1].view(np.uint32))
+        out[sched] = frames[0]
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+
+
 def test_phase_time_variant_keeps_pixels_and_reports_cycles():
     """stats_mode 2: the shipped march plus a clock read at every phase change"""
     case = CASES["amr_grad"]()
