@@ -1322,7 +1322,8 @@ static void render_pixel(Ctx *C, int px, int py, int W, int H, uint32_t *rgba, f
   v3 color = V3(pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x,   /* :1701 */
                 pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y,
                 pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z);
-  /* clockScale heat-map (:1703-1707) reads the GPU cycle counter; not reproducible, not restated */
+  /* clockScale heat-map (:1703-1707) reads the GPU cycle counter; not reproducible, not restated here (the HIP
+   * kernels implement it; tests/test_gpu_parity.py::test_clock_heat_map checks its range and that g, b are untouched) */
   if (frameID > 0) {                                                         /* :1709-1710 */
     color.x += accum4[4 * pixelIdx + 0];
     color.y += accum4[4 * pixelIdx + 1];

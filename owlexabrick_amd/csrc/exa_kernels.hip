@@ -60,6 +60,15 @@ template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { r
 template <bool FAST> __device__ __forceinline__ float fsqrt(float a) { return FAST ? __builtin_amdgcn_sqrtf(a) : sqrtf(a); }
 
 struct Ray { V3 org, dir; float tmin, tmax; };
+
+// exabrick.cu:1588,1703-1707: the viewer's clock heat map — red = clockScale * (cycles this ray's program ran) / 1e6.
+// The start stamp is wave-uniform and stays in scalar registers; with a surfaces pre-pass only the march is timed.
+__device__ __forceinline__ float clockHeat(float clockScale, unsigned long long clockBegin)
+{
+  const unsigned long long absClock = clock64() - clockBegin;
+  const float relClock = clockScale * (float)absClock / 1000000.f;
+  return fminf(relClock, 1.f);
+}
 struct Color4 { float x, y, z, w; };
 
 // per-thread view of the kernel state.  STATS: 0 = the shipped kernel, 1 = work counters (sample for sample the
@@ -880,6 +889,7 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
   C.xfLds = xfLds;
   C.stack = stackLds + threadIdx.x;
   C.guardTripped = false;
+  const unsigned long long clockBegin = clock64();                              // :1588
   if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
 
   // tile -> pixel: wave w covers the 8x8 block (w&1, w>>1) of the 16x16 tile
@@ -985,6 +995,7 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
     float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;    // :1701
     float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
     float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
+    if (fs.clockScale > 0.f) cr = clockHeat(fs.clockScale, clockBegin);          // :1703-1707
 
     // framebuffer slot: row-major for a whole frame, tile-major inside a shard
     const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
@@ -1428,6 +1439,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
   C.xfLds = xfLds;
   C.stack = stackRef + threadIdx.x;
   C.guardTripped = false;
+  const unsigned long long clockBegin = clock64();                              // :1588
   if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
   __shared__ unsigned long long lapMarks[STATS == 2 ? 8 * (kKdBlock / 64) : 1];
   if (STATS == 2) {
@@ -1631,6 +1643,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
     float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
     float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
+    if (fs.clockScale > 0.f) cr = clockHeat(fs.clockScale, clockBegin);          // :1703-1707
     if (frameID > 0) {
       const float4 acc = a.accum[slot];
       cr += acc.x; cg += acc.y; cb += acc.z;
@@ -1691,6 +1704,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   C.xfLds = xfLds;
   C.stack = stackRef + threadIdx.x;
   C.guardTripped = false;
+  const unsigned long long clockBegin = clock64();                              // :1588
 
   // these waves are the frame's critical path: let them issue ahead of the one-lane march they share SIMDs with
   __builtin_amdgcn_s_setprio(3);
@@ -1897,6 +1911,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
       float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
       float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
+      if (fs.clockScale > 0.f) cr = clockHeat(fs.clockScale, clockBegin);          // :1703-1707
       if (frameID > 0) {
         const float4 acc = a.accum[slot];
         cr += acc.x; cg += acc.y; cb += acc.z;

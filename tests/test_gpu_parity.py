@@ -227,6 +227,25 @@ def test_scheduling_edge_cases(what):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
 
 
+@pytest.mark.parametrize("accel", [1, 0], ids=["kd", "lbvh"])
+def test_clock_heat_map(accel):
+    """frameState.clockScale > 0 (exabrick.cu:1703-1707): red = clockScale * cycles / 1e6 clamped to 1, green and
+    blue untouched"""
+    case = Case(_amr(), W=96, H=64, grad=1, accel=accel)
+    plain = case.run_hip()[1]
+    R = case.hip_renderer()
+    R.frameState.clockScale = 1e9          # saturates: every pixel's program runs more than a thousandth of a cycle
+    R.render()
+    hot = R.readAccum()
+    R.frameState.clockScale = 1e-3         # a million cycles would be 1e-3: tiny but positive for marched pixels
+    R.render()
+    warm = R.readAccum()
+    R.close()
+    assert np.array_equal(hot[..., 1:3], plain[..., 1:3]) and np.array_equal(warm[..., 1:3], plain[..., 1:3])
+    assert np.all(hot[..., 0] == 1.0)
+    assert np.all(warm[..., 0] > 0.0) and np.all(warm[..., 0] < 1.0)
+
+
 def test_phase_time_variant_keeps_pixels_and_reports_cycles():
     """stats_mode 2: the shipped march plus a clock read at every phase change"""
     case = CASES["amr_grad"]()
