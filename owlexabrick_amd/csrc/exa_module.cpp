@@ -409,9 +409,9 @@ struct ExaHipRenderer {
     if (wideMode == 2 || wideMode == 4) {
       (wideMode == 4 ? w4 : w2) = curMap;
     } else if (wideMode == 1 && costOfTile) {
-      // measured on C4 / MI355X (tests/gpu_shard_scaling.py): a critical tile finishes 1.33x / 1.64x
-      // sooner with 2 / 4 lanes per ray and costs 1.47x / 2.19x the work; a loaded GPU steps a wave 1.3x slower
-      const double kSpeed2 = 1.33, kWork2 = 1.47, kWork4 = 2.19, kLoaded = 1.3;   // (4 lanes: 1.64x sooner)
+      // measured on C4 / MI355X: a critical tile finishes 1.28x / 1.59x sooner with 2 / 4 lanes per
+      // ray and costs 1.50x / 2.24x the work; a loaded GPU steps a wave 1.3x slower
+      const double kSpeed2 = 1.28, kWork2 = 1.50, kWork4 = 2.24, kLoaded = 1.3;
       double fill = 0;
       for (size_t b = 0; b < n; b++) fill += 4.0 * (*costOfTile)[curMap[b]];
       fill *= kLoaded / numSimdWaves;
