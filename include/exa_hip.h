@@ -242,7 +242,8 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * change of view / TF / layout the next synchronous frame records every tile's longest ray and later frames launch
  * the heaviest tiles first (a frame's critical path is its longest rays), 0 = keep the static order; "wide_march" 1
  * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes
- * per ray — consecutive samples evaluated side by side, composited in order, bit-identical pixels — 0 = never,
+ * per ray — the walk split into depth windows, consecutive samples evaluated side by side and composited in order,
+ * bit-identical pixels; up to 8 GiB of device memory for the walkers' leaf lists — 0 = never,
  * 2 / 4 = every tile with that many lanes (tests); "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
  * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change.
  * One knob moves results within the stated float tolerance: "fast_math" 1 (default)

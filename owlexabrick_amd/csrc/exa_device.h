@@ -61,7 +61,8 @@ struct DeviceScene {
 };
 
 enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 4, kSegQueue = 4,
-       kKdBlock = 256 };   // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
+       kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
+       kWideSegCap = 256 };   // wide march: leaves a window walker lists per round (16 B each; a fuller window takes more rounds)
 
 enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CORNER_LOADS,
                 ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES,
@@ -110,6 +111,7 @@ struct RenderArgs {
   int32_t           *errorFlag;     // set when a loop guard trips
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
   const int32_t     *wideTileMap;   // wide march: launch slot / L -> global tile id
+  float4            *wideSegs;      // wide march: [tile of this launch][ray][window][kWideSegCap] {record, tn, tf, -}
   uint32_t          *tileCost;      // != null: per tile id, brick visits of the tile's longest ray (launch-order feedback)
 };
 

@@ -1686,6 +1686,63 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
 // Used for the tiles the launch-order feedback marks as critical (exa_module: reorderFromCosts);
 // single primary channel only.
 // ------------------------------------------------------------------------
+// One step of a window walker of the wide march: the kd walk of kdStep (same stages, same order of leaves) that
+// records every leaf whose entry distance lies in [winLo, winHi) as {record, tn, tf} in `out` instead of testing it
+// against the march's running tmin — that test needs the end of the previous accepted segment, which a walker of a
+// later window does not know yet; the march applies it when it consumes the list.  Subtrees that end before the
+// window are skipped, the walk ends with the first one that starts behind it.
+__device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float winLo, const float winHi, const RenderArgs &a,
+                                              float *stackF, const Ray &ray, const KdNodeDev *nodes, const int root,
+                                              float4 *out, unsigned &count)
+{
+  if (w.ref != EXA_KD_EMPTY && !(w.tn < winHi)) { w.ref = EXA_KD_DONE; return; }
+  if (w.ref < 0 && w.ref > EXA_KD_DONE) {
+    if (w.tn >= winLo && w.tn < w.tf) out[count++] = make_float4(__int_as_float(~w.ref), w.tn, w.tf, 0.f);   // caller: count < cap
+    w.ref = EXA_KD_EMPTY;
+  }
+  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > winLo))) kdPop(C, w, root, stackF);
+  if (w.ref < 0 || !(w.tf > winLo) || !(w.tn < winHi)) return;
+  const int4 n = *reinterpret_cast<const int4 *>(nodes + w.ref);
+  const float split = __int_as_float(n.x);
+  const int axis = n.y & 3;
+  const int bits = (n.y >> 2) & 3;                            // volume activity: bit0 left, bit1 right
+  const float ox = ray.org.x, oy = ray.org.y, oz = ray.org.z, dx = ray.dir.x, dy = ray.dir.y, dz = ray.dir.z;
+  float o = axis == 0 ? ox : oy, d = axis == 0 ? dx : dy;
+  o = axis == 2 ? oz : o;
+  d = axis == 2 ? dz : d;
+  if (d == 0.f) {
+    if (o < split && (bits & 1)) w.ref = n.z;
+    else if (o > split && (bits & 2)) w.ref = n.w;
+    else kdPop(C, w, root, stackF);
+    return;
+  }
+  const float ts = (split - o) / d;
+  const bool nearIsLeft = d > 0.f;
+  const int nearRef = nearIsLeft ? n.z : n.w, farRef = nearIsLeft ? n.w : n.z;
+  const bool nearAct = (bits & (nearIsLeft ? 1 : 2)) != 0, farAct = (bits & (nearIsLeft ? 2 : 1)) != 0;
+  if (ts >= w.tf) {
+    if (nearAct) w.ref = nearRef; else kdPop(C, w, root, stackF);
+  } else if (ts <= w.tn) {
+    if (farAct) w.ref = farRef; else kdPop(C, w, root, stackF);
+  } else if (nearAct) {
+    if (farAct) {
+      const int head = w.pk.get(PK_SHEAD), count_ = w.pk.get(PK_SCOUNT);
+      C.stack[head * kKdBlock] = farRef;
+      stackF[(2 * head) * kKdBlock] = ts;
+      stackF[(2 * head + 1) * kKdBlock] = w.tf;
+      w.pk.set(PK_SHEAD, head == kKdStack - 1 ? 0 : head + 1);
+      if (count_ == kKdStack) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count_ + 1);
+    }
+    w.ref = nearRef;
+    w.tf = ts;
+  } else if (farAct) {
+    w.ref = farRef;
+    w.tn = ts;
+  } else {
+    kdPop(C, w, root, stackF);
+  }
+}
+
 template <bool GRAD, bool FAST, bool SURF, int L>
 __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const RenderArgs a)
 {
@@ -1694,8 +1751,6 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
   float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
-  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
-  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
@@ -1713,7 +1768,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   const int part = blockIdx.x % L;
   const int tx = tile % a.tilesX, ty = tile / a.tilesX;
   const int lane = threadIdx.x & 63, sub = lane & (L - 1), lead = lane & ~(L - 1);
-  const bool leader = sub == 0;
+  const bool leader = sub == 0;                        // writes the pixel
   const int r = part * (kTilePixels / L) + (threadIdx.x >> 6) * (64 / L) + lane / L;     // ray of the tile
   const int inX = (((r >> 6) & 1) << 3) + (r & 7), inY = ((r >> 7) << 3) + ((r >> 3) & 7);   // 8x8 block order, as the one-lane kernel
   const int px = tx * kTile + inX, py = ty * kTile + inY;
@@ -1755,11 +1810,15 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
 
     Color4 pixelColor; pixelColor.x = pixelColor.y = pixelColor.z = pixelColor.w = 0.f;
 
-    KdWalk w;
+    // ---- phase 1: every lane of the ray walks one window of it.  The root interval is cut into L windows by
+    //      entry distance; lane `sub` lists the leaves that start in window `sub`, whole (a leaf is never split),
+    //      in HBM.  All 64 lanes of the wave walk at once, where the one-lane march walks with a quarter of them.
+    float4 *const mySegs = a.wideSegs + (size_t(blockIdx.x / L) * kTilePixels * L + size_t(r) * L + sub) * kWideSegCap;
+    unsigned myCount = 0;
+    KdWalk w;                            // stays alive: a window with more leaves than its list holds is walked in rounds
     w.pk.v = 0;
-    w.tn = w.tf = w.tEnd = 0.f;
-    w.ref = EXA_KD_DONE;
-    if (leader) {
+    float winLo, winHi;
+    {
       Ray whole = ray; whole.tmin = -INFINITY; whole.tmax = INFINITY;
       float r0, r1;
       const bool hit = boxTest(whole, mk(a.kdLo), mk(a.kdHi), r0, r1);
@@ -1767,8 +1826,21 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       w.tf = fminf(r1, ray.tmax);
       w.tEnd = w.tf;
       w.ref = (hit && w.tn < w.tf) ? a.kdMarchRoot : EXA_KD_DONE;
+      const float span = w.tf - w.tn;
+      winLo = sub == 0 ? -INFINITY : w.tn + span * (float(sub) / float(L));
+      winHi = sub == L - 1 ? INFINITY : w.tn + span * (float(sub + 1) / float(L));
+      for (unsigned g = 0;; g++) {
+        if (g == 0xfffffff0u) { C.guardTripped = true; break; }
+        const bool want = w.ref != EXA_KD_DONE && myCount < kWideSegCap;
+        if (!__any(want)) break;
+        if (want) kdCollectStep(C, w, winLo, winHi, a, stackF, ray, a.kdMarchNodes, a.kdMarchRoot, mySegs, myCount);
+      }
     }
+    // ---- phase 2: the march consumes the lists in order ----
     float walkTmin = ray.tmin;
+    int curWin = 0;
+    unsigned curIdx = 0, curCount = (unsigned)__shfl((int)myCount, lead, 64);
+    const float4 *curSegs = a.wideSegs + (size_t(blockIdx.x / L) * kTilePixels * L + size_t(r) * L) * kWideSegCap;
 
     bool haveSeg = false, newStep = false, needHdr = false, mine = false;
     int listBegin = 0, listSize = 0;
@@ -1783,33 +1855,45 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
 
     for (unsigned iter = 0;; iter++) {
       if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
-      // ---- refill burst, leaders only ----
-      if (__any(leader && !haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
-        for (;;) {
-          const bool want = leader && w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
-          if (!__any(want)) break;
-          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
-        }
-      }
       if (!haveSeg) {
-        // ---- next segment: the leader pops, the ray's lanes share it ----
+        // ---- next segment: the next listed leaf that passes the reference's test against the running tmin
+        //      (t0 = max(tmin, tn) < t1, then tmin = t1 * 1.0000001f: exabrick.cu:197-210, :1698); all lanes of the
+        //      ray read the same entry ----
         int region = -1;
-        float t0 = 0.f, tEnd = 0.f;
-        if (leader) {
-          const int qc = w.pk.get(PK_QCOUNT);
-          if (qc > 0) {
-            const int qh = w.pk.get(PK_QHEAD);
-            region = qRegion[qh * kKdBlock];
-            t0 = qT[(2 * qh) * kKdBlock];
-            tEnd = qT[(2 * qh + 1) * kKdBlock];
-            w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
-            w.pk.set(PK_QCOUNT, qc - 1);
+        float t0 = 0.f;
+        for (;;) {
+          if (curIdx >= curCount) {
+            // list of window curWin used up.  Its walker may have stopped at a full list: next round for that lane
+            // (the other lanes of the ray wait; rare), otherwise on to the next window
+            const bool mineIsCur = sub == curWin;
+            if (__shfl((int)(w.ref != EXA_KD_DONE), lead + curWin, 64)) {
+              if (mineIsCur) {
+                myCount = 0;
+                for (unsigned g = 0; w.ref != EXA_KD_DONE && myCount < kWideSegCap; g++) {
+                  if (g == 0xfffffff0u) { C.guardTripped = true; break; }
+                  kdCollectStep(C, w, winLo, winHi, a, stackF, ray, a.kdMarchNodes, a.kdMarchRoot, mySegs, myCount);
+                }
+              }
+              curIdx = 0;
+              curCount = (unsigned)__shfl((int)myCount, lead + curWin, 64);
+              continue;
+            }
+            if (++curWin == L) break;
+            curIdx = 0;
+            curCount = (unsigned)__shfl((int)myCount, lead + min(curWin, L - 1), 64);
+            curSegs += kWideSegCap;
+            continue;
+          }
+          const float4 e = curSegs[curIdx++];
+          t0 = fmaxf(walkTmin, e.y);
+          if (t0 < e.z) {
+            region = __float_as_int(e.x);
+            t1 = e.z;
+            walkTmin = t1 * (1.0000001f);
+            break;
           }
         }
-        region = __shfl(region, lead, 64);
-        if (region < 0) break;                                                     // walk finished: ray done
-        t0 = __shfl(t0, lead, 64);
-        t1 = __shfl(tEnd, lead, 64);
+        if (curWin == L) break;                                                    // lists exhausted: ray done
         if (a.leafBeginBits) {
           // the leaf reference of the march tree is the region's record itself: no load between the queue and
           // the first brick record

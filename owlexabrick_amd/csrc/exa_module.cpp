@@ -243,6 +243,7 @@ struct ExaHipRenderer {
   int wideMode = 1;                     // option wide_march: 0 off, 1 by cost, 2 / 4 every tile with that many lanes (tests)
   int numSimdWaves = 256 * 4 * 6;       // waves the device holds at the march kernel's occupancy
   DevBuf<int32_t> normalMap, wideMap;   // one-lane tiles in launch order; wide tiles, the 4-lane ones first
+  DevBuf<float4> wideSegs;              // leaf lists of the wide march's window walkers (grown on demand)
   int nNormal = 0, nWide4 = 0, nWide2 = 0;
   hipStream_t side4 = nullptr, side2 = nullptr, sideN = nullptr;
   hipEvent_t evFork = nullptr, evJoin4 = nullptr, evJoin2 = nullptr, evJoinN = nullptr;
@@ -409,9 +410,9 @@ struct ExaHipRenderer {
     if (wideMode == 2 || wideMode == 4) {
       (wideMode == 4 ? w4 : w2) = curMap;
     } else if (wideMode == 1 && costOfTile) {
-      // measured on C4 / MI355X: a critical tile finishes 1.28x / 1.59x sooner with 2 / 4 lanes per
-      // ray and costs 1.50x / 2.24x the work; a loaded GPU steps a wave 1.3x slower
-      const double kSpeed2 = 1.28, kWork2 = 1.50, kWork4 = 2.24, kLoaded = 1.3;
+      // measured on C4 / MI355X: a critical tile finishes 1.63x / 2.36x sooner with 2 / 4 lanes per
+      // ray and costs 1.49x / 1.88x the work; a loaded GPU steps a wave 1.3x slower
+      const double kSpeed2 = 1.63, kWork2 = 1.49, kWork4 = 1.88, kLoaded = 1.3;
       double fill = 0;
       for (size_t b = 0; b < n; b++) fill += 4.0 * (*costOfTile)[curMap[b]];
       fill *= kLoaded / numSimdWaves;
@@ -428,9 +429,23 @@ struct ExaHipRenderer {
     } else {
       normal = curMap;
     }
-    if (wideMode != 2 && wideMode != 4 && w4.empty() && w2.empty()) { nNormal = (int)n; nWide4 = nWide2 = 0; return 0; }
+    {
+      // leaf lists: 16 B x kWideSegCap per window walker = 8 KiB per lane; keep them within 8 GiB by handing the
+      // lightest wide tiles back to the one-lane march (forced modes on large frames)
+      const size_t perTile4 = size_t(kTilePixels) * 4 * kWideSegCap * sizeof(float4), perTile2 = perTile4 / 2;
+      const size_t budget = size_t(std::getenv("EXA_WIDE_BUDGET_GB") ? std::atoi(std::getenv("EXA_WIDE_BUDGET_GB")) : 8) << 30;
+      while (w4.size() * perTile4 + w2.size() * perTile2 > budget) {
+        if (!w2.empty()) { normal.push_back(w2.back()); w2.pop_back(); }
+        else { normal.push_back(w4.back()); w4.pop_back(); }
+      }
+    }
+    if (w4.empty() && w2.empty()) { nNormal = (int)n; nWide4 = nWide2 = 0; return 0; }
     std::vector<int32_t> wide(w4);
     wide.insert(wide.end(), w2.begin(), w2.end());
+    {
+      const size_t need = (w4.size() * 4 + w2.size() * 2) * size_t(kTilePixels) * kWideSegCap;
+      if (need > wideSegs.n) HIP_TRY(this, wideSegs.alloc(need));
+    }
     HIP_TRY(this, normalMap.refill(normal.data(), normal.size()));
     HIP_TRY(this, wideMap.refill(wide.data(), wide.size()));
     nNormal = (int)normal.size(); nWide4 = (int)w4.size(); nWide2 = (int)w2.size();
@@ -654,12 +669,14 @@ struct ExaHipRenderer {
         if (nWide4) {
           HIP_TRY(this, hipStreamWaitEvent(side4, evFork, 0));
           aw.wideTileMap = wideMap.p;
+          aw.wideSegs = wideSegs.p;
           HIP_TRY(this, launchRenderKdWide(aw, nWide4, 4, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side4));
           HIP_TRY(this, hipEventRecord(evJoin4, side4));
         }
         if (nWide2) {
           HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
           aw.wideTileMap = wideMap.p + nWide4;
+          aw.wideSegs = wideSegs.p + size_t(nWide4) * 4 * kTilePixels * kWideSegCap;
           HIP_TRY(this, launchRenderKdWide(aw, nWide2, 2, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side2));
           HIP_TRY(this, hipEventRecord(evJoin2, side2));
         }
