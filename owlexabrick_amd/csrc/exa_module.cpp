@@ -444,7 +444,13 @@ struct ExaHipRenderer {
     wide.insert(wide.end(), w2.begin(), w2.end());
     {
       const size_t need = (w4.size() * 4 + w2.size() * 2) * size_t(kTilePixels) * kWideSegCap;
-      if (need > wideSegs.n) HIP_TRY(this, wideSegs.alloc(need));
+      if (need > wideSegs.n && wideSegs.alloc(need) != hipSuccess) {
+        // no room for the leaf lists: the frame simply keeps the one-lane march
+        (void)hipGetLastError();
+        wideSegs.release();
+        nNormal = (int)n; nWide4 = nWide2 = 0;
+        return 0;
+      }
     }
     HIP_TRY(this, normalMap.refill(normal.data(), normal.size()));
     HIP_TRY(this, wideMap.refill(wide.data(), wide.size()));
