@@ -1682,7 +1682,8 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
 // consecutive samples of the segment at once and then composite them in order (every lane does the
 // same ten operations on the same values, so all copies of the pixel stay identical and no lane has
 // to be told about an early termination).  Same samples, same arithmetic, same order as the one-lane
-// march: the pixels are bit-identical.  Lane 0 of a ray owns the kd walk and the segment queue.
+// march: the pixels are bit-identical.  The walk is parallel as well: every lane of the ray lists the leaves of one
+// depth window of it in HBM first (kdCollectStep below), then the lists are marched in order.
 // Used for the tiles the launch-order feedback marks as critical (exa_module: reorderFromCosts);
 // single primary channel only.
 // ------------------------------------------------------------------------
