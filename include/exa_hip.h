@@ -3,7 +3,7 @@
  * This is the drop-in boundary for the reference's `exa::OptixRenderer`
  * (exa/OptixRenderer.h:32-97) and the device programs it launches
  * (programs/exabrick.cu).  Plain pointers and sizes only; no C++/torch types.
- * The C++ facade `exa::Renderer` (owlexabrick_amd/host/Renderer.h) keeps the
+ * The C++ facade `exa::Renderer` (owlexabrick_amd/host/exa_host.h) keeps the
  * OptixRenderer method names on top of these entry points; INTEGRATION.md shows
  * the binding a maintainer of the reference would add.
  *
