@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of the ExaBrick DVR hot path on MI355X.
 
-One step = one frame: region-LBVH traversal + adaptive ray march + compositing of
+One step = one frame: region kd-tree walk + adaptive ray march + compositing of
 every pixel of a 2048x2048 frame of the exajet-like scene (BASELINE.json
 configs[3] as a seeded procedural stand-in), scene resident in HBM.
 With N GPUs the frame is split into interleaved 16x16 tiles, one process per GPU,
@@ -9,7 +9,10 @@ and the RGBA8 tiles are gathered to rank 0 over RCCL (strong scaling: the frame
 is fixed).  Prints ONE JSON line on rank 0.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--scale S] [--size PX]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`python bench.py --gpus N` starts its own N ranks (fresh child processes, started before this
+process imports torch or touches a GPU); under `python -m torch.distributed.run --nproc-per-node N`
+(RANK / WORLD_SIZE in the environment) it is one of the ranks.
 """
 import argparse
 import json
@@ -32,8 +35,8 @@ def log(*a):
 
 def algorithmic_bytes(st, pixels, frame_id=0):
     """per brick visit 32 B record + 4 B leaf-list entry, 4 B per cell
-    scalar actually read, per segment the 44 B region record + 64 B per LBVH node
-    fetched, per pixel 4 B RGBA8 + 16 B accum write (+16 B accum read after frame 0)."""
+    scalar actually read, per segment the 44 B region record + node_bytes per node of the structure
+    that was walked, per pixel 4 B RGBA8 + 16 B accum write (+16 B accum read after frame 0)."""
     return (36 * (st["brick_visits"]) + 4 * st["corner_loads"]
             + 44 * (st["segments"] + st["iso_segments"]) + st.get("node_bytes", 64) * st["nodes_visited"]
             + pixels * (4 + 16 + (16 if frame_id > 0 else 0)))
@@ -58,6 +61,41 @@ def effective_cpus():
     return n
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` without a launcher: start N fresh rank processes and wait for them.  Called before this
+    process has imported torch or made any GPU call; the children are new interpreters (never an exec of a process
+    that has touched the GPU).  Rank 0 prints the JSON line on the inherited stdout.  A failed rank ends the others
+    and the exit code is non-zero; nothing is retried."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), EXA_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC (RCCL between processes)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"[bench] rank process {procs.index(p)} (pid {p.pid}) exited with {code}; stopping the others",
+                      file=sys.stderr, flush=True)
+                for q in live:
+                    q.terminate()                                # exact PIDs of our own children
+    return rc if rc >= 0 else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,13 +115,29 @@ def main():
     ap.add_argument("--ao", action="store_true", help="ambient-occlusion rays on surface hits (2 per hit, reference default)")
     ap.add_argument("--spp", type=int, default=1, help="frames accumulated per step (frameID 0..spp-1); a step is one converged frame")
     ap.add_argument("--dump", default=None, help="write the frame as PNG (rank 0)")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="exa_hip_set_option (tuning knobs)")
+    ap.add_argument("--spawn-check", action="store_true",
+                    help="every rank prints its RANK/WORLD_SIZE/MASTER_* as one JSON line and exits (no GPU; tests)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+    if args.spawn_check:
+        print(json.dumps({"rank": rank, "world": world, "local_rank": local_rank, "pid": os.getpid(), "ppid": os.getppid(),
+                          "master": f"{os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}",
+                          "torch_imported": "torch" in sys.modules}), flush=True)
+        if os.environ.get("EXA_BENCH_FAIL_RANK") == str(rank):
+            sys.exit(7)
+        if os.environ.get("EXA_BENCH_FAIL_RANK"):
+            time.sleep(30)                      # a healthy rank waiting in a collective: the parent must end it
+        return
+    if world != args.gpus:
+        # the launcher's world size is what runs; say so instead of printing a line that claims --gpus
+        log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; this is a {world}-rank run")
 
     import numpy as np
     import torch
@@ -97,6 +151,8 @@ def main():
     backend = os.environ.get("EXA_BENCH_BACKEND", "nccl")
     if os.environ.get("EXA_BENCH_ONE_DEVICE"):
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -105,6 +161,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where collectives operate
 
     W = H = args.size
@@ -147,6 +204,9 @@ def main():
     R.resizeFrameBuffer((W, H))
     R.setOption("tile_order", args.tile_order)
     R.setOption("accel", args.accel)
+    for kv in args.option:
+        k, v = kv.split("=")
+        R.setOption(k, int(v))
     R.setShard(rank, world)
     R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
     R.updateXF(0, xf[:, 3], xf[:, :3], scene.value_range, 1.0)
@@ -162,47 +222,69 @@ def main():
     R.frameState.ao.enabled = 1 if args.ao else 0
     R.updateFrameID(0)
 
-    n_out = R.outputPixels()
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     stride = ((tiles + world - 1) // world) * 256 if world > 1 else W * H
-    shard = torch.zeros(stride, dtype=torch.int32, device=dev)
+    # Two shard buffers: while the shard of frame k travels to rank 0, frame k+1 is already being marched into the
+    # other one (the accumulation buffer is not read at frameID 0, and with spp > 1 the gather waits for the last
+    # sample anyway).  EXA_BENCH_PIPELINE=0 keeps every frame synchronous, like owlLaunch2D.
+    pipelined = world > 1 and backend == "nccl" and os.environ.get("EXA_BENCH_PIPELINE", "1") != "0"
+    shards = [torch.zeros(stride, dtype=torch.int32, device=dev) for _ in range(2 if pipelined else 1)]
     final = torch.zeros(W * H, dtype=torch.int32, device=dev) if (world > 1 and rank == 0) else None
     # rank 0 receives every shard straight into its slice of one flat buffer (no concatenation step)
     gathered_flat = torch.zeros(stride * world, dtype=torch.int32, device=dev) if (world > 1 and rank == 0) else None
     gathered = list(gathered_flat.chunk(world)) if gathered_flat is not None else None
-    mode = {"collective": "gather"}
+    render_stream = torch.cuda.Stream(device=dev) if pipelined else None
+    comm_stream = torch.cuda.Stream(device=dev) if pipelined else None
+    rendered = [torch.cuda.Event() for _ in shards]
+    consumed = [torch.cuda.Event() for _ in shards]
+    frame_no = [0]
 
     def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        for f in range(args.spp):                                      # viewer.cpp:279-288, one launch per sample
+        k = frame_no[0] % len(shards)
+        frame_no[0] += 1
+        shard = shards[k]
+        if not pipelined:
+            stream = torch.cuda.current_stream().cuda_stream
+            for f in range(args.spp):                                      # viewer.cpp:279-288, one launch per sample
+                if args.spp > 1:
+                    R.updateFrameID(f)
+                R.render(device_ptr=shard.data_ptr(), stream=stream)       # synchronous, like owlLaunch2D
+            if world == 1:
+                return
+            if backend == "nccl":
+                dist.gather(shard, gathered, dst=0)           # each peer -> root over its own xGMI link
+            else:
+                host = shard.cpu()
+                hl = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                dist.gather(host, hl, dst=0)
+                if rank == 0:
+                    gathered_flat.copy_(torch.cat(hl))
+            if rank == 0:
+                R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=stream)
+            return
+        # pipelined: the march goes to the render stream and returns at once; the gather + untile of this frame are
+        # queued on the communication stream behind it and overlap the next frame's march
+        render_stream.wait_event(consumed[k])                              # the buffer's previous gather is done
+        for f in range(args.spp):
             if args.spp > 1:
                 R.updateFrameID(f)
-            R.render(device_ptr=shard.data_ptr(), stream=stream)       # synchronous, like owlLaunch2D
-        if world == 1:
-            return
-        if backend == "nccl":
-            if mode["collective"] == "gather":
-                try:
-                    dist.gather(shard, gathered, dst=0)       # each peer -> root over its own xGMI link
-                except RuntimeError as e:                     # defensive: fall back to an all-gather
-                    log(f"dist.gather failed ({e}); using all_gather_into_tensor")
-                    mode["collective"] = "all_gather"
-                    mode["flat"] = gathered_flat if rank == 0 else torch.zeros(stride * world, dtype=torch.int32, device=dev)
-            if mode["collective"] == "all_gather":
-                dist.all_gather_into_tensor(mode["flat"], shard)
-        else:
-            host = shard.cpu()
-            hl = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
-            dist.gather(host, hl, dst=0)
+            R.render(device_ptr=shard.data_ptr(), stream=render_stream.cuda_stream, async_=True)
+        rendered[k].record(render_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(rendered[k])
+            dist.gather(shard, gathered, dst=0)
             if rank == 0:
-                gathered_flat.copy_(torch.cat(hl))
-        if rank == 0:
-            R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=stream)
+                R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=comm_stream.cuda_stream)
+            consumed[k].record(comm_stream)
 
     # work counters of this frame (instrumented kernel variant, frameID 0)
     R.updateFrameID(0)
     _, st = R.renderStats()
     log("stats:", {k: v for k, v in st.items() if k not in ("kernel_ms", "rebuild_ms")})
+    # the first frames are synchronous in every mode: the launch-order feedback measures tile costs on a
+    # synchronous frame and re-orders the launch
+    for _ in range(2):
+        R.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -213,7 +295,8 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(R.stats()["kernel_ms"])       # the step's last launch
+        if not pipelined:
+            kernel_ms.append(R.stats()["kernel_ms"])       # the step's last launch
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -222,6 +305,12 @@ def main():
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    if pipelined:
+        # kernel time per launch (HIP events on the launch stream), measured after the timed region on
+        # synchronous frames: an asynchronous launch's events are not read back inside the loop
+        for _ in range(min(5, max(2, args.steps))):
+            R.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            kernel_ms.append(R.stats()["kernel_ms"])
 
     # aggregate per-rank work counters and kernel time
     agg = torch.tensor([st["samples"], st["brick_visits"], st["corner_loads"], st["segments"], st["nodes_visited"],
@@ -237,21 +326,28 @@ def main():
         k_ms = float(np.mean(kernel_ms))                   # this rank's launches (HIP events on the launch stream)
         B = algorithmic_bytes(st, st["pixels"], 0)         # per launch of this rank
         achieved = B / (k_ms * 1e-3) / 1e9
+        cfg = scenes.CONFIGS[args.config]
         out = {
             "metric": f"frames/sec at {W}^2 DVR{'+iso' if args.iso is not None else ''}{'+AO' if args.ao else ''}"
                       f"{', %d spp' % args.spp if args.spp > 1 else ''}, {args.config.split('_', 1)[1]}-like, MI355X",
             "value": fps, "unit": "frames/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "msamples_per_s": samples_total / 1e6 * fps * args.spp,
-            "config": {"workload": f"{args.config} (seed 0xE7A0003 procedural AMR, scale {args.scale}): "
+            "config": {"workload": f"{args.config} (seed {cfg['seed']:#x} procedural AMR, scale {args.scale}): "
                                    f"{scene.num_cells} cells / {scene.bricks7.shape[0]} bricks / "
                                    f"{int(prep.scene.numRegions)} regions, {W}x{H} DVR, dt 0.5, alpha ramp, "
                                    f"gradient shading {'off' if args.no_grad else 'on'}, space skipping on, frameID 0",
-                       "tiling": f"16x16 tiles interleaved over {world} GPU(s)" + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "tiling": f"16x16 tiles interleaved over {world} GPU(s)"
+                                 + (f", {'RCCL (nccl)' if backend == 'nccl' else backend} gather to rank 0"
+                                    f"{', overlapped with the next frame' if pipelined else ''}" if world > 1 else ""),
+                       "backend": backend if world > 1 else None,
                        "samples_per_frame": samples_total, "kernel_ms_max_over_ranks": float(kmax.item())},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            # Three views of the same launch: `achieved`/`frac` is SURVEY 8(d)'s formula — bytes the
+            # lanes REQUEST (most are served by L1/L2) over kernel time, against the HBM peak; `hbm_measured` is what
+            # reaches HBM according to the PMC counters; `valu_issue` is the resource that binds the kernel.
+            "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "renderFrameKdKernel" if args.accel else "renderFrameKernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": B,
@@ -262,21 +358,31 @@ def main():
                                              "framebuffer": 20 * st["pixels"]}},
         }
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(traffic_file):
+        key = f"{args.config}@{args.scale}@{W}"
+        if os.path.exists(traffic_file) and world == 1 and args.iso is None and args.spp == 1:
             try:
                 tf = json.load(open(traffic_file))
-                out["roofline"]["traffic"] = tf.get(f"{args.config}@{args.scale}@{W}")
-                vi = tf.get(f"{args.config}@{args.scale}@{W}:valu_wave_instructions")
+                traffic = tf.get(key)
+                out["roofline"]["traffic"] = traffic
+                out["roofline"]["pmc_source"] = tf.get(key + ":note")
+                if traffic:
+                    gbs = traffic / (k_ms * 1e-3) / 1e9
+                    out["roofline"]["hbm_measured"] = {"achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                                       "requested_over_fetched": B / traffic}
+                vi = tf.get(key + ":valu_wave_instructions")
                 if vi:
-                    # what actually bounds the kernel: vector-instruction issue.  A wave64 VALU
-                    # instruction holds a SIMD for 2 cycles (MI355X_MICROARCH.md); 256 CUs x 4 SIMDs at 2.4 GHz
+                    # what bounds the kernel: vector-instruction issue.  A wave64 VALU instruction holds a SIMD
+                    # for 2 cycles (MI355X_MICROARCH.md, wave scheduling); 256 CUs x 4 SIMDs at 2.4 GHz
                     floor_ms = vi * 2.0 / (256 * 4) / 2.4e9 * 1e3
                     out["roofline"]["valu_issue"] = {"wave_instructions": vi, "floor_ms": floor_ms, "frac": floor_ms / k_ms,
-                                                     "source": "SQ_INSTS_VALU, profiles/ (same command under rocprofv3 --pmc)"}
-            except Exception:
-                pass
+                                                     "peak": "1024 SIMDs x 1 wave64 VALU instruction / 2 cycles at 2.4 GHz",
+                                                     "source": "SQ_INSTS_VALU of the same command under rocprofv3 --pmc (profiles/)"}
+            except Exception as e:  # noqa: BLE001
+                log(f"could not read {traffic_file}: {e}")
+        if "valu_issue" not in out["roofline"]:
+            out["roofline"]["bound"] = "hbm"       # no counter file for this configuration: only the formula view
         if args.dump:
-            img = (final if world > 1 else shard).cpu().numpy().view(np.uint32).reshape(H, W)
+            img = (final if world > 1 else shards[0]).cpu().numpy().view(np.uint32).reshape(H, W)
             harness.write_png(args.dump, img)
 
         # ---------------- CPU baseline: the oracle on a bounded crop ----------------
@@ -309,11 +415,21 @@ def main():
                                              f"oracle scene build {oracle_box['build_s']:.0f}s not included",
                                    "msamples_per_s": st_c["samples"] / 1e6 / t_cpu}
             # the crop doubles as a full-size parity check of the GPU frame
-            img = shard.cpu().numpy().view(np.uint32).reshape(H, W)
+            img = shards[0].cpu().numpy().view(np.uint32).reshape(H, W)
             d = np.abs(harness.unpack_rgba8(img[x0:x0 + side, x0:x0 + side]).astype(int)
                        - harness.unpack_rgba8(rgba_c[x0:x0 + side, x0:x0 + side]).astype(int))
             out["cpu_baseline"]["crop_max_abs_diff_rgba8"] = int(d.max())
             out["cpu_baseline"]["crop_pixels_differing"] = int((d.max(axis=-1) > 0).sum())
+            # the one-thread figure beside the all-threads one (a smaller crop, ~10 s)
+            side1 = int(min(side, max(32, side * (10.0 / max(t_cpu * cores, 1e-3)) ** 0.5))) // 16 * 16
+            x1 = (W - side1) // 2
+            t = time.perf_counter()
+            _, _, st_1 = S.render(fs, P, W, H, window=(x1, x1, x1 + side1, x1 + side1), nthreads=1)
+            t_1 = time.perf_counter() - t
+            out["cpu_baseline"]["one_thread"] = {
+                "value": 1.0 / (t_1 * samples_total / max(1, st_1["samples"])), "unit": "frames/s", "cores": 1,
+                "msamples_per_s": st_1["samples"] / 1e6 / t_1,
+                "sample": f"{side1}x{side1} centre crop ({st_1['samples']} samples, {t_1:.1f}s on 1 thread), scaled by sample count"}
         print(json.dumps(out), flush=True)
 
     if world > 1:

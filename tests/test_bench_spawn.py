@@ -1,0 +1,47 @@
+"""`python bench.py --gpus N` starts its own N ranks: fresh child processes with
+RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*, started before the parent imports torch; a failed rank ends the
+others and the exit code is non-zero.  `--spawn-check` makes every rank report and exit without a GPU."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+from common import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(kw)
+    return env
+
+
+def test_gpus_n_starts_n_ranks_without_a_launcher():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--spawn-check"], env=_env(), capture_output=True,
+                         text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert sorted(r["rank"] for r in rows) == [0, 1, 2, 3]
+    assert all(r["world"] == 4 and r["local_rank"] == r["rank"] for r in rows)
+    assert len({r["master"] for r in rows}) == 1 and rows[0]["master"].startswith("127.0.0.1:")
+    assert len({r["pid"] for r in rows}) == 4 and len({r["ppid"] for r in rows}) == 1     # children of one parent
+    assert not any(r["torch_imported"] for r in rows)
+
+
+def test_under_a_launcher_it_is_one_rank():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--spawn-check"],
+                         env=_env(RANK="3", LOCAL_RANK="3", WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT="1"),
+                         capture_output=True, text=True, timeout=60)
+    rows = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    assert out.returncode == 0 and len(rows) == 1 and rows[0]["rank"] == 3 and rows[0]["world"] == 8
+
+
+def test_a_failed_rank_ends_the_job_with_a_non_zero_exit():
+    t0 = time.time()
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "3", "--spawn-check"], env=_env(EXA_BENCH_FAIL_RANK="1"),
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 7
+    assert "exited with 7" in out.stderr
+    assert time.time() - t0 < 25          # the healthy ranks (sleeping 30 s) were ended, not waited for
