@@ -246,9 +246,12 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * bit-identical pixels; up to 8 GiB of device memory for the walkers' leaf lists — 0 = never,
  * 2 / 4 = every tile with that many lanes (tests); "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
  * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change.
- * One knob moves results within the stated float tolerance: "fast_math" 1 (default)
+ * Two knobs move results within the stated float tolerance: "fast_math" 1 (default)
  * evaluates the opacity correction powf as exp2(dt*log2(x)) on the hardware
- * transcendental units (~2 ulp), 0 uses the library powf (<1 ulp). */
+ * transcendental units (~2 ulp), 0 uses the library powf (<1 ulp); "tf_filter" 1 (default) holds the
+ * transfer-function filter weight in 9-bit fixed point with 8 fractional bits, as the CUDA texture unit
+ * behind the reference's tex1D<float4> fetch does (programs/exabrick.cu:147, exa/Texture.h:141-147; CUDA C
+ * programming guide, "Texture Fetching", linear filtering), 0 keeps the full-precision weight. */
 int exa_hip_set_option(ExaHipRenderer *, const char *key, int32_t value);
 
 const char *exa_hip_last_error(const ExaHipRenderer * /* may be NULL: creation errors */);

@@ -101,6 +101,7 @@ struct OrScene {
   int32_t  *leafList; size_t numLeaf, capLeaf;
   KdNode   *nodes; size_t numNodes, capNodes;
   float     xf[OR_MAX_CHANNELS][OR_NUM_XF_VALUES][4];
+  float     tfFracMagic;   /* 32768: filter fraction held in 1.8 fixed point (CUDA tex1D); 0: full precision */
   float    *meshVerts; int32_t *meshTris; size_t numVerts, numTris;   /* all surfaces, concatenated */
   /* streamline tracer state (OptixRenderer.h:160-170) */
   int tracerEnabled, tracerChannels[3], numTraces, numTimesteps, timestep;
@@ -277,6 +278,7 @@ OrScene *or_scene_create(const int32_t *bricks7, size_t numBricks,
   if (!S) die_oom();
   S->numBricks = numBricks;
   S->numFields = numFields;
+  S->tfFracMagic = 32768.f;           /* default: the published CUDA linear filter */
   S->bricks = (OrBrick *)xmalloc(numBricks * sizeof(OrBrick));
   /* exa/OptixRenderer.cpp:75-93 flatten */
   size_t scalarOffset = 0;
@@ -399,6 +401,10 @@ void or_set_triangles(OrScene *S, const float *verts, size_t numVerts, const int
 void or_set_xf(OrScene *S, int chan, const float *rgba128)
 { memcpy(S->xf[chan], rgba128, sizeof(S->xf[chan])); }
 
+/* 1 (default): the tex1D filter weight in 9-bit fixed point with 8 fractional bits, as the CUDA C
+ * programming guide publishes it; 0: full-precision weight */
+void or_set_tf_filter(OrScene *S, int cudaFixedPoint) { S->tfFracMagic = cudaFixedPoint ? 32768.f : 0.f; }
+
 /* ------------------------------------------------------------------ */
 /* pixel helpers                                                       */
 /* ------------------------------------------------------------------ */
@@ -437,15 +443,20 @@ static inline float clampf(float f, float lo, float hi) { return fminf(hi, fmaxf
 static inline int clampi(int f, int lo, int hi) { int m = f > lo ? f : lo; return m < hi ? m : hi; }
 
 /* tex1D<float4> on a 128-texel cudaArray, linear filter, clamp addressing,
- * normalized coordinates (exa/Texture.h:141-147): x = u*N - 0.5,
- * i = floor(x), a = x - i, T[clamp(i)]*(1-a) + T[clamp(i+1)]*a.  The NVIDIA
- * unit quantises 'a' to 8 fractional bits; that is not observable offline and
- * is deliberately not emulated ("parity unpinned"). */
-static inline v4 tex1d_linear(const float (*T)[4], float u)
+ * normalized coordinates (exa/Texture.h:141-147; fetch at exabrick.cu:147).  The filter itself
+ * runs in NVIDIA's texture unit, outside the reference tree; restated from the CUDA C
+ * programming guide, appendix "Texture Fetching", "Linear Filtering":
+ *     tex(x) = (1 - a) T[i] + a T[i+1],  i = floor(xB), a = frac(xB), xB = x - 0.5, x = N u
+ * "a is stored in 9-bit fixed point format with 8 bits of fractional value (so 1.0 is exactly
+ * represented)".  The guide gives the format, not the rounding: the fraction is rounded to the
+ * NEAREST multiple of 1/256 here (ties to even) — adding 2^15 to a float in [0,1) leaves exactly 8
+ * fractional bits.  fracMagic = 0 keeps the full-precision weight (or_set_tf_filter). */
+static inline v4 tex1d_linear(const float (*T)[4], float u, float fracMagic)
 {
   float x = u * (float)OR_NUM_XF_VALUES - 0.5f;
   float fl = floorf(x);
-  float a = x - fl;
+  volatile float aq = (x - fl) + fracMagic;      /* volatile: the sum is rounded to binary32 before the subtraction */
+  float a = aq - fracMagic;
   int i0 = clampi(f2i(fl), 0, OR_NUM_XF_VALUES - 1);
   int i1 = clampi(f2i(fl) + 1, 0, OR_NUM_XF_VALUES - 1);
   float na = 1.f - a;
@@ -464,7 +475,7 @@ static inline v4 lookup_xf(const OrScene *S, const OrFrameState *fs, float in_sc
   float scalar = (OR_NUM_XF_VALUES - 1) * (in_scalar - lo) / ((hi - lo) + 1e-20f);
   scalar = clampf(scalar + .5f, 0.f, OR_NUM_XF_VALUES - 1.f);
   scalar /= OR_NUM_XF_VALUES - 1.f;
-  v4 r = tex1d_linear(S->xf[channel], scalar);
+  v4 r = tex1d_linear(S->xf[channel], scalar, S->tfFracMagic);
   r.w *= fs->xfOpacityScale;
   return r;
 }

@@ -91,6 +91,7 @@ def lib():
             getattr(L, n).argtypes = [vp]
         L.or_voxel_bounds.argtypes = [vp, fp, fp]
         L.or_set_xf.argtypes = [vp, C.c_int, vp]
+        L.or_set_tf_filter.argtypes = [vp, C.c_int]
         L.or_set_triangles.argtypes = [vp, vp, sz, vp, sz]
         L.or_reset_tracer.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, vp]
         L.or_advance_tracer.restype = C.c_int
@@ -188,6 +189,10 @@ class OracleScene:
     def set_xf(self, chan, rgba128):
         a = np.ascontiguousarray(rgba128, dtype=np.float32).reshape(128, 4)
         lib().or_set_xf(self.h, chan, a.ctypes.data)
+
+    def set_tf_filter(self, cuda_fixed_point):
+        """1 (default) = CUDA tex1D filter weight in 1.8 fixed point, 0 = full precision"""
+        lib().or_set_tf_filter(self.h, int(cuda_fixed_point))
 
     def reset_tracer(self, enabled, channels, num_traces, num_timesteps, steplen, seeds):
         sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(num_traces, 3)

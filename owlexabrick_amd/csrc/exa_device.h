@@ -99,6 +99,7 @@ struct RenderArgs {
   ExaHipFrameState   fs;
   ExaHipParams       p;
   const float4      *xf;            // numXfChannels x 128 (r,g,b,a)
+  float              tfFracMagic;   // 2^15: TF filter weight rounded to 8 fractional bits (CUDA tex1D), 0: full precision
   int32_t            numXfChannels;
   int32_t            W, H, tilesX, tilesY;
   int32_t            rank, world;   // image-space shard
@@ -118,7 +119,7 @@ struct RenderArgs {
 // ---- launchers implemented in exa_kernels.hip ----
 hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s);
 hipError_t launchVolumeActivity(const DeviceScene &sc, const ExaHipFrameState &fs, const ExaHipParams &p,
-                                const float4 *xf, uint8_t *active, hipStream_t s);
+                                const float4 *xf, uint8_t *active, float tfFracMagic, hipStream_t s);
 hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, uint8_t *active, hipStream_t s);
 // refit one height class of internal nodes: box of each child = union below it
 hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,

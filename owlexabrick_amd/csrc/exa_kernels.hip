@@ -119,12 +119,16 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b)
 { return (make_8bit(r) << 0) + (make_8bit(g) << 8) + (make_8bit(b) << 16) + (0xffu << 24); }
 
 // ------------------------------------------------------------------------
-// exabrick.cu:135-150 lookupTransferFunction; the tex1D<float4> fetch
-// (128 texels, linear, clamp, normalized coords) is a software lerp on the
-// LDS-resident table: x = u*128-0.5, T[i]*(1-a) + T[i+1]*a.
+// exabrick.cu:135-150 lookupTransferFunction; the tex1D<float4> fetch (128 texels, linear, clamp,
+// normalized coords; exa/Texture.h:141-147) is a software lerp on the LDS-resident table:
+// x = u*128-0.5, T[i]*(1-a) + T[i+1]*a.  The CUDA programming guide ("Texture Fetching", linear
+// filtering) publishes that the unit holds the weight a in 9-bit fixed point with 8 fractional bits:
+// fracMagic = 2^15 rounds a to the nearest 1/256 (a float in [2^15, 2^16) has exactly 8 fractional
+// bits), fracMagic = 0 keeps the full-precision weight (option tf_filter).
 // ------------------------------------------------------------------------
 template <bool FAST = false>
-__device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameState &fs, float in_scalar, int channel)
+__device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameState &fs, float in_scalar, int channel,
+                                           const float fracMagic)
 {
   const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
   float scalar = fdiv<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
@@ -132,7 +136,7 @@ __device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameSt
   scalar = fdiv<FAST>(scalar, EXA_NUM_XF_VALUES - 1.f);
   const float x = scalar * float(EXA_NUM_XF_VALUES) - 0.5f;
   const float fl = floorf(x);
-  const float al = x - fl;
+  const float al = ((x - fl) + fracMagic) - fracMagic;
   const int i0 = min(EXA_NUM_XF_VALUES - 1, max(0, int(fl)));
   const int i1 = min(EXA_NUM_XF_VALUES - 1, max(0, int(fl) + 1));
   const float4 T0 = xf[channel * EXA_NUM_XF_VALUES + i0];
@@ -396,7 +400,7 @@ template <bool FAST, int STATS>
 __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, float actual_dt, float cellValue, V3 gradient,
                                               int finestLevelCellWidth, int channel)
 {
-  Color4 sample = lookupXF<FAST>(C.xfLds, C.a->fs, cellValue, channel);
+  Color4 sample = lookupXF<FAST>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic);
   if (fsqrt<FAST>(dot(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
     const float scale = fdiv<FAST>(fabsf(dot(lightDir, gradient)), fsqrt<FAST>(dot(gradient, gradient) * dot(lightDir, lightDir)));
@@ -501,21 +505,21 @@ __device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, cons
         C.count(ST_ISO_EVALS);
         if (C.a->p.gradientShadingISO) {
           if (samplePoint<true, STATS>(C, cellValue, grad, ri, isopt, fs.iso[i].channel)) {
-            sample = lookupXF(C.xfLds, fs, cellValue, fs.iso[i].channel);
+            sample = lookupXF(C.xfLds, fs, cellValue, fs.iso[i].channel, C.a->tfFracMagic);
             grad = normalize(grad);
             if (dot(grad, ray.dir) > 0.f) grad = -grad;
           }
         } else {
           V3 unused;
           if (samplePoint<false, STATS>(C, cellValue, unused, ri, isopt, fs.iso[i].channel))
-            sample = lookupXF(C.xfLds, fs, cellValue, fs.iso[i].channel);
+            sample = lookupXF(C.xfLds, fs, cellValue, fs.iso[i].channel, C.a->tfFracMagic);
         }
         if (C.a->p.colormapChannel != 0) {
           cellValue = 0.f;
           V3 unused;
           C.count(ST_ISO_EVALS);
           if (samplePoint<false, STATS>(C, cellValue, unused, ri, isopt, C.a->p.colormapChannel))
-            sample = lookupXF(C.xfLds, fs, cellValue, 0);
+            sample = lookupXF(C.xfLds, fs, cellValue, 0, C.a->tfFracMagic);
         }
         sample.w = 1.f;
         if (!isfinite(grad.x) || !isfinite(grad.y) || !isfinite(grad.z)) grad = mk(0.f, 0.f, 0.f);
@@ -618,7 +622,7 @@ __device__ SurfaceHit traceContourRay(Ctx<STATS> &C, const Ray &ray, V3 normal, 
     V3 unused;
     samplePoint<false, STATS>(C, value, unused, C.a->sc.regionInfo[region], pos, 0);   // :1396, channel 0
   }
-  const Color4 sample = lookupXF(C.xfLds, C.a->fs, value, channel);
+  const Color4 sample = lookupXF(C.xfLds, C.a->fs, value, channel, C.a->tfFracMagic);
   prd.primID = EXA_PRIMID_PLANE;
   prd.t_hit = t;
   prd.Ng = normal;
@@ -1837,6 +1841,11 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
         if (want) kdCollectStep(C, w, winLo, winHi, a, stackF, ray, a.kdMarchNodes, a.kdMarchRoot, mySegs, myCount);
       }
     }
+    // The lists go from the lane that wrote them to the other lanes of the ray through global memory: release here,
+    // acquire in front of the reads (wavefront scope — writer and readers are lanes of one wave; no instruction is
+    // generated, the fences pin the order the compiler may not change)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // ---- phase 2: the march consumes the lists in order ----
     float walkTmin = ray.tmin;
     int curWin = 0;
@@ -1875,6 +1884,8 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
                   kdCollectStep(C, w, winLo, winHi, a, stackF, ray, a.kdMarchNodes, a.kdMarchRoot, mySegs, myCount);
                 }
               }
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // refilled list: writer lane -> reader lanes
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
               curIdx = 0;
               curCount = (unsigned)__shfl((int)myCount, lead + curWin, 64);
               continue;
@@ -2160,7 +2171,7 @@ hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hi
 // Region activity: the OPTIX_BOUNDS_PROGRAMs (exabrick.cu:250-312, 373-402)
 // ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void volumeActivityKernel(DeviceScene sc, ExaHipFrameState fs, ExaHipParams p,
-                                                            const float4 *xf, uint8_t *active)
+                                                            const float4 *xf, uint8_t *active, float tfFracMagic)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -2182,7 +2193,7 @@ __global__ __launch_bounds__(256) void volumeActivityKernel(DeviceScene sc, ExaH
       float cellValue = float(i) / (EXA_NUM_XF_VALUES - 1);
       cellValue *= dhi - dlo;
       cellValue += dlo;
-      const Color4 rgba = lookupXF(xfLds, fs, cellValue, c);
+      const Color4 rgba = lookupXF(xfLds, fs, cellValue, c, tfFracMagic);
       if (rgba.w > 0.f) { act = true; break; }
     }
   }
@@ -2201,11 +2212,11 @@ __global__ __launch_bounds__(256) void isoActivityKernel(DeviceScene sc, ExaHipF
 }
 
 hipError_t launchVolumeActivity(const DeviceScene &sc, const ExaHipFrameState &fs, const ExaHipParams &p,
-                                const float4 *xf, uint8_t *active, hipStream_t s)
+                                const float4 *xf, uint8_t *active, float tfFracMagic, hipStream_t s)
 {
   if (sc.numRegions == 0) return hipSuccess;
   const size_t lds = size_t(p.numChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
-  hipLaunchKernelGGL(volumeActivityKernel, dim3((sc.numRegions + 255) / 256), dim3(256), lds, s, sc, fs, p, xf, active);
+  hipLaunchKernelGGL(volumeActivityKernel, dim3((sc.numRegions + 255) / 256), dim3(256), lds, s, sc, fs, p, xf, active, tfFracMagic);
   return hipGetLastError();
 }
 hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, uint8_t *active, hipStream_t s)

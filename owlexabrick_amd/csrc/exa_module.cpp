@@ -131,6 +131,21 @@ struct LbvhTopology {
   }
 };
 
+// The ABI calls run on the handle's device and leave the caller's current device as they found it.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceGuard(int device)
+  {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    err = hipSetDevice(device);
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define EXA_ON_DEVICE(h) DeviceGuard guard_((h)->device); HIP_TRY(h, guard_.err)
+
 template <typename T>
 struct DevBuf {
   T *p = nullptr;
@@ -232,6 +247,8 @@ struct ExaHipRenderer {
   int tileOrder = 4;                 // Z-order launch sequence (measured best on C4)
   int debugPixel = -1;
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
+  int tfFilter = 1;                  // TF filter weight in 1.8 fixed point as CUDA's tex1D (0: full precision)
+  float tfFracMagic() const { return tfFilter ? 32768.f : 0.f; }
   DevBuf<float4> accum;
   DevBuf<float4> surf;
   DevBuf<uint32_t> tileCost;            // launch-order feedback, one entry per tile of the image
@@ -538,7 +555,7 @@ struct ExaHipRenderer {
     if (volDirty || (needIso && isoDirty)) {
       HIP_TRY(this, hipEventRecord(ev2, s));
       if (volDirty) {                       // needVolumeBVHRebuild (OptixRenderer.cpp:533-537)
-        HIP_TRY(this, launchVolumeActivity(sc, fs, p, xf.p, volActive.p, s));
+        HIP_TRY(this, launchVolumeActivity(sc, fs, p, xf.p, volActive.p, tfFracMagic(), s));
         if (lbvhBuilt && refit(volNodes, volActive.p, s)) return 1;
         if (haveKd && kdRefit(volActive.p, 0, s)) return 1;
         volDirty = false;
@@ -620,6 +637,7 @@ struct ExaHipRenderer {
     a.fs = fs;
     a.p = p;
     a.xf = xf.p;
+    a.tfFracMagic = tfFracMagic();
     a.numXfChannels = numFields;
     a.W = W; a.H = H; a.tilesX = tilesX; a.tilesY = tilesY;
     a.rank = rank; a.world = world;
@@ -728,7 +746,8 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   h->device = device;
   auto bail = [&]() { g_createError = h->err; delete h; return 1; };
 #define CREATE_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->fail(std::string(#call) + ": " + hipGetErrorString(e_)); return bail(); } } while (0)
-  CREATE_TRY(hipSetDevice(device));
+  DeviceGuard guard_(device);
+  CREATE_TRY(guard_.err);
 
   // validate indices on the host before anything can fault on the device
   for (uint64_t i = 0; i < scene->leafListSize; i++)
@@ -918,7 +937,7 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
 int exa_hip_destroy(ExaHipRenderer *h)
 {
   if (!h) return 0;
-  (void)hipSetDevice(h->device);
+  DeviceGuard guard_(h->device);
   (void)hipDeviceSynchronize();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -938,7 +957,7 @@ int exa_hip_resize(ExaHipRenderer *h, int32_t width, int32_t height)
 {
   if (!h) return 1;
   if (width <= 0 || height <= 0 || int64_t(width) * height > (int64_t(1) << 30)) { h->fail("exa_hip_resize: bad size"); return 1; }
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   h->W = width; h->H = height;
   h->layoutDirty = true;
   return h->rebuildLayout();
@@ -976,7 +995,7 @@ int exa_hip_set_triangles(ExaHipRenderer *h, const float *vertices, uint64_t num
                           const int32_t *triangles, uint64_t numTris)
 {
   if (!h) return 1;
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   HIP_TRY(h, hipDeviceSynchronize());
   h->numTris = 0;
   h->meshNodes.release(); h->meshVerts.release(); h->meshTris.release();
@@ -1027,7 +1046,7 @@ int exa_hip_reset_tracer(ExaHipRenderer *h, const ExaHipTracer *t, const float *
   if (t->numTraces < 0 || t->numTimesteps < 2 || (long long)t->numTraces * t->numTimesteps > (1ll << 28)) { h->fail("exa_hip_reset_tracer: bad trace counts"); return 1; }
   for (int k = 0; k < 3; k++)
     if (t->channels[k] < 0 || t->channels[k] >= h->numFields) { h->fail("exa_hip_reset_tracer: tracer channel out of range"); return 1; }
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   HIP_TRY(h, hipDeviceSynchronize());
   h->tracer = *t;
   h->haveTracer = true;
@@ -1060,7 +1079,7 @@ int exa_hip_advance_tracer(ExaHipRenderer *h, int32_t *rebuild)
 int exa_hip_read_traces(ExaHipRenderer *h, float *dst)
 {
   if (!h || !dst || !h->haveTracer) return 1;
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipMemcpy(dst, h->traces.p, h->traces.n * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
@@ -1084,7 +1103,7 @@ int exa_hip_set_shard(ExaHipRenderer *h, int32_t rank, int32_t worldSize)
   if (worldSize < 1 || rank < 0 || rank >= worldSize) { h->fail("exa_hip_set_shard: bad rank/world"); return 1; }
   h->rank = rank; h->world = worldSize;
   h->layoutDirty = true;
-  if (h->W > 0) { HIP_TRY(h, hipSetDevice(h->device)); return h->rebuildLayout(); }
+  if (h->W > 0) { EXA_ON_DEVICE(h); return h->rebuildLayout(); }
   return 0;
 }
 
@@ -1104,6 +1123,11 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
+  if (!std::strcmp(key, "tf_filter")) {
+    if (value != 0 && value != 1) { h->fail("exa_hip_set_option: tf_filter is 0 or 1"); return 1; }
+    if (value != h->tfFilter) { h->tfFilter = value; h->volDirty = true; }     // region activity goes through the TF lookup
+    return 0;
+  }
   h->fail(std::string("exa_hip_set_option: unknown key ") + key);
   return 1;
 }
@@ -1117,7 +1141,7 @@ uint64_t exa_hip_output_pixels(const ExaHipRenderer *h)
 static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, hipStream_t s, bool async, bool stats)
 {
   if (!h) return 1;
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   if (h->prepareFrame(s)) return 1;
   uint32_t *dst = dstIsDevice && rgba8 ? rgba8 : h->color.p;
   if (stats) HIP_TRY(h, hipMemsetAsync(h->statsBuf.p, 0, ST_COUNT * sizeof(unsigned long long), s));
@@ -1173,7 +1197,7 @@ int exa_hip_untile(ExaHipRenderer *h, const uint32_t *gathered, uint64_t shardSt
                    int32_t worldSize, uint32_t *rgba8_out, void *hipStream)
 {
   if (!h || !gathered || !rgba8_out || worldSize < 1) return 1;
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   HIP_TRY(h, launchUntile(gathered, shardStridePixels, worldSize, h->W, h->H, rgba8_out, (hipStream_t)hipStream));
   return 0;
 }
@@ -1181,7 +1205,7 @@ int exa_hip_untile(ExaHipRenderer *h, const uint32_t *gathered, uint64_t shardSt
 int exa_hip_read_accum(ExaHipRenderer *h, float *dst4)
 {
   if (!h || !dst4) return 1;
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   HIP_TRY(h, hipMemcpy(dst4, h->accum.p, h->accum.n * sizeof(float4), hipMemcpyDeviceToHost));
   return 0;
 }
@@ -1189,7 +1213,7 @@ int exa_hip_read_accum(ExaHipRenderer *h, float *dst4)
 int exa_hip_write_accum(ExaHipRenderer *h, const float *src4)
 {
   if (!h || !src4) return 1;
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   HIP_TRY(h, hipMemcpy(h->accum.p, src4, h->accum.n * sizeof(float4), hipMemcpyHostToDevice));
   return 0;
 }
@@ -1197,7 +1221,7 @@ int exa_hip_write_accum(ExaHipRenderer *h, const float *src4)
 int exa_hip_read_activity(ExaHipRenderer *h, int32_t which, uint8_t *dst)
 {
   if (!h || !dst) return 1;
-  HIP_TRY(h, hipSetDevice(h->device));
+  EXA_ON_DEVICE(h);
   if (h->prepareFrame(nullptr)) return 1;
   if (which == 1 && !h->isoEnabled()) {     // evaluate on demand
     HIP_TRY(h, launchIsoActivity(h->sc, h->fs, h->isoActive.p, nullptr));

@@ -30,7 +30,8 @@ def band_xf(lo=0.35, hi=0.65):
 class Case:
     def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
                  space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
-                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None, contour=None, meshes=None):
+                 xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None, contour=None, meshes=None,
+                 tf_filter=None):
         self.scene, self.W, self.H = scene, W, H
         self.grad, self.iso, self.dt = grad, iso, dt
         self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
@@ -40,6 +41,7 @@ class Case:
         self.accel = accel
         self.fast_math = fast_math
         self.contour = contour
+        self.tf_filter = tf_filter    # None = default (CUDA 1.8 fixed-point filter weight); 0 = full-precision weight
         self.meshes = meshes          # list of (verts[n,3], tris[m,3]), world space
         nf = len(scene.fields)
         self.nprim = nf if multi else 1
@@ -66,6 +68,8 @@ class Case:
                            num_region_fields=len(self.scene.fields) if self.multi else 1)
         for c, xf in enumerate(self.xfs):
             S.set_xf(c, xf)
+        if self.tf_filter is not None:
+            S.set_tf_filter(self.tf_filter)
         if self.meshes:
             S.set_triangles(*self._merged_meshes())
         return S
@@ -110,6 +114,8 @@ class Case:
             R.setOption("accel", self.accel)
         if self.fast_math is not None:
             R.setOption("fast_math", self.fast_math)
+        if self.tf_filter is not None:
+            R.setOption("tf_filter", self.tf_filter)
         for k, v in getattr(self, "options", {}).items():
             R.setOption(k, v)
         lo, hi = prep.voxel_bounds()

@@ -4,7 +4,7 @@
    tools/artificial generator (built by oracle/ref.mk into oracle/_ref/) on its own
    ex0..ex4.grids inputs — data, not source.
 2. oracle_*.npz: frames rendered by the CPU oracle on those inputs (RGBA8, float accum,
-   work counters, region table).  The reference has no goldens of its own (no tests at
+   work counters, region table) — ORACLE-derived, not reference-derived.  The reference has no goldens of its own (no tests at
    all), so these pin the oracle against regressions and pin the HIP path on the GPU box.
 """
 import os
@@ -34,6 +34,10 @@ GOLDEN_CASES = {
     "ex4_grad_iso2": ("ex4", dict(W=64, H=48, grad=1, iso=[(0.3, 0), (0.7, 0)])),
     "ex4_accum3": ("ex4", dict(W=64, H=48, grad=1, frames=3)),
     "ex3_contour_iso": ("ex3", dict(W=64, H=48, grad=1, iso=[(0.6, 0)], contour=[([1, 1, 0.2], 0.55, 0)], opacity_scale=0.2)),
+    # BASELINE.json configs[0]: 64^3 single-level brick with the ex2 corner pattern, 512x512, viewer
+    # default camera / TF / dt, gradient shading off and on; the fixture holds the centre 192x192 crop of the frame
+    "c1_64_512": ("c1_64", dict(W=512, H=512, window=(160, 160, 352, 352))),
+    "c1_64_512_grad": ("c1_64", dict(W=512, H=512, grad=1, window=(160, 160, 352, 352))),
 }
 
 
@@ -41,9 +45,22 @@ def make_case(name):
     scn, kw = GOLDEN_CASES[name]
     kw = dict(kw)
     frames = kw.pop("frames", 1)
+    kw.pop("window", None)
     if kw.get("xf") == "band":
         kw["xf"] = band_xf()
     return Case(scenes.example(scn), **kw), frames
+
+
+def golden_window(name):
+    """(x0, y0, x1, y1) of the crop the fixture holds, or None for the whole frame"""
+    return GOLDEN_CASES[name][1].get("window")
+
+
+def crop(a, window):
+    if window is None:
+        return a
+    x0, y0, x1, y1 = window
+    return a[y0:y1, x0:x1]
 
 
 def main():
@@ -57,7 +74,9 @@ def main():
                                   stdout=subprocess.DEVNULL)
     for name in GOLDEN_CASES:
         case, frames = make_case(name)
-        rgba, acc, st = case.run_oracle(nthreads=1, frames=frames)
+        win = golden_window(name)
+        rgba, acc, st = case.run_oracle(nthreads=1, frames=frames, window=win)
+        rgba, acc = crop(rgba, win), crop(acc, win)
         S = case.oracle_scene()
         np.savez_compressed(os.path.join(HERE, f"oracle_{name}.npz"), rgba=rgba, accum=acc,
                             stats=np.array([st[k] for k in sorted(st)], dtype=np.int64),

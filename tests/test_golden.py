@@ -8,14 +8,16 @@ import pytest
 from common import ROOT
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-from make_golden import GOLDEN_CASES, make_case  # noqa: E402
+from make_golden import GOLDEN_CASES, crop, golden_window, make_case  # noqa: E402
 
 
 @pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
 def test_oracle_reproduces_golden(name):
     g = np.load(os.path.join(ROOT, "tests", "golden", f"oracle_{name}.npz"))
     case, frames = make_case(name)
-    rgba, acc, st = case.run_oracle(nthreads=3, frames=frames)
+    win = golden_window(name)
+    rgba, acc, st = case.run_oracle(nthreads=3, frames=frames, window=win)
+    rgba, acc = crop(rgba, win), crop(acc, win)
     S = case.oracle_scene()
     assert S.regions().tobytes() == g["regions"].tobytes()
     assert np.array_equal(S.leaflist(), g["leaflist"])

@@ -1,0 +1,215 @@
+"""Every BASELINE.json configuration at its own size, through the C ABI with the options a caller gets by default
+(C1 is the committed golden `c1_64_512*` in test_gpu_parity.py):
+
+  C2  LANL-like          1024x1024 DVR
+  C3  landing-gear-like  2048x2048 DVR (2 channels) + one implicit iso-surface
+  C4  exajet-like, full  2048x2048 DVR                      (the bench line's workload)
+  C5  exajet-like, full  4096x4096 DVR + iso-surface + AO, frames 0..15 accumulated
+
+For each: (a) the oracle on a 96x96 crop where the rays are dense and on one across the silhouette, under the
+tolerance of tests/common.py; (b) properties that need no oracle at full size: the kd walk and the LBVH restart pick
+the same segments (bit-equal frames with the library powf), space skipping is image-neutral (KAT-7), launch order,
+launch-order feedback and the wide march never change a pixel (also as rank 0 of 8, where the wide march engages)."""
+import numpy as np
+import pytest
+
+from common import ACCUM_ATOL, ACCUM_RTOL, FLIP_BOUND, Case, po
+from owlexabrick_amd import harness, scenes
+
+pytestmark = pytest.mark.gpu
+
+CROP = 96
+
+
+def _windows(acc, W, H):
+    """a fully covered CROP x CROP window nearest the image centre, and the one whose coverage is closest to one half
+    (the silhouette), both on a 32-pixel grid; deterministic functions of the rendered frame"""
+    cov = (acc[..., :3].sum(axis=-1) > 0).astype(np.float64)
+    ii = np.zeros((H + 1, W + 1))
+    ii[1:, 1:] = cov.cumsum(0).cumsum(1)
+    best_dense, best_sil = None, None
+    for y0 in range(0, H - CROP + 1, 32):
+        for x0 in range(0, W - CROP + 1, 32):
+            f = (ii[y0 + CROP, x0 + CROP] - ii[y0, x0 + CROP] - ii[y0 + CROP, x0] + ii[y0, x0]) / (CROP * CROP)
+            dc = (x0 + CROP / 2 - W / 2) ** 2 + (y0 + CROP / 2 - H / 2) ** 2
+            if f == 1.0 and (best_dense is None or dc < best_dense[0]):
+                best_dense = (dc, x0, y0)
+            key = (abs(f - 0.5), dc)
+            if 0.2 < f < 0.8 and (best_sil is None or key < best_sil[0]):
+                best_sil = (key, x0, y0)
+    assert best_dense is not None and best_sil is not None, "frame has no dense / silhouette window"
+    return {"dense": (best_dense[1], best_dense[2], best_dense[1] + CROP, best_dense[2] + CROP),
+            "silhouette": (best_sil[1], best_sil[2], best_sil[1] + CROP, best_sil[2] + CROP)}
+
+
+def _check_crop(acc_gpu, acc_cpu, win, frames, ao, what):
+    x0, y0, x1, y1 = win
+    g, o = acc_gpu[y0:y1, x0:x1].astype(np.float64), acc_cpu[y0:y1, x0:x1].astype(np.float64)
+    d = np.abs(g - o)
+    tol = frames * ACCUM_ATOL + ACCUM_RTOL * np.abs(o)
+    bad = int((d > tol).any(axis=-1).sum())
+    n = d.shape[0] * d.shape[1]
+    if ao:
+        # an AO ray that flips hit/miss (cosf/sinf ulps) moves its frame's sample by half the surface colour
+        assert bad <= max(5, int(0.004 * n * frames ** 0.5)), (what, bad, float(d.max()))
+        return
+    # termination flips only (tests/common.py): rare, and bounded by the transmittance left at 0.98
+    assert bad <= max(5, int(1e-3 * n * frames)), (what, bad, float(d.max()))
+    assert d.max() <= FLIP_BOUND * frames, (what, float(d.max()))
+    assert o[..., :3].sum() > 0, what
+
+
+class Config:
+    """one scene, one oracle scene, one renderer — built once per configuration"""
+
+    def __init__(self, name, size, iso=None, ao=0, scale=1.0):
+        self.sc = scenes.config(name, scale=scale)
+        nf = len(self.sc.fields)
+        self.case = Case(self.sc, W=size, H=size, grad=1, iso=iso, ao=ao, xf_domains=[(0.0, 1.0)] * nf)
+        self.R = self.case.hip_renderer()
+        self.S = None
+
+    def oracle(self):
+        if self.S is None:
+            self.S = self.case.oracle_scene()
+        return self.S
+
+    def render_frames(self, frames=1):
+        rgba = None
+        for f in range(frames):
+            self.R.updateFrameID(f)
+            rgba = self.R.render()
+        return rgba, self.R.readAccum()
+
+    def oracle_frames(self, win, frames=1, nthreads=16):
+        S, acc = self.oracle(), None
+        for f in range(frames):
+            fs, P = self.case.oracle_state(S, frameID=f)
+            _, acc, st = S.render(fs, P, self.case.W, self.case.H, window=win, accum=acc, nthreads=nthreads)
+        return acc
+
+    def close(self):
+        self.R.close()
+        self.S = None
+
+
+def _same(a, b):
+    return np.array_equal(a[0], b[0]) and np.array_equal(a[1].view(np.uint32), b[1].view(np.uint32))
+
+
+def _properties(cfg, frames=1, lbvh=True):
+    R = cfg.R
+    R.updateFrameID(0)
+    base = cfg.render_frames(frames)
+    # ---- kd walk == LBVH restart, library powf (identical segments, samples and arithmetic) ----
+    if lbvh:
+        R.setOption("fast_math", 0)
+        kd0 = cfg.render_frames(1)
+        R.setOption("accel", 0)
+        lb0 = cfg.render_frames(1)
+        R.setOption("accel", 1)
+        R.setOption("fast_math", 1)
+        assert _same(kd0, lb0)
+    # ---- launch order / feedback / wide march never change a pixel ----
+    for order in (0, 5):
+        R.setOption("tile_order", order)
+        assert _same(cfg.render_frames(frames), base), f"tile_order {order}"
+    R.setOption("tile_order", 4)
+    R.setOption("tile_feedback", 0)
+    R.setOption("wide_march", 0)
+    assert _same(cfg.render_frames(frames), base), "static order, one lane per ray"
+    # as rank 0 of an 8-GPU job the feedback marks the critical tiles and the wide march takes them
+    R.setShard(0, 8)
+    static = cfg.render_frames(frames)
+    R.setOption("tile_feedback", 1)
+    R.setOption("wide_march", 1)
+    for _ in range(3):                                   # measure, re-order + assign, steady state
+        assert _same(cfg.render_frames(frames), static), "shard 0/8 with feedback + wide march"
+    R.setShard(0, 1)
+    # ---- KAT-7 at full size: space skipping is image-neutral ----
+    with_skip = cfg.render_frames(1)
+    R.setSpaceSkipping(False)
+    no_skip = cfg.render_frames(1)
+    R.setSpaceSkipping(True)
+    assert np.abs(with_skip[1] - no_skip[1]).max() < 1e-5
+    return base
+
+
+def _oracle_crops(cfg, base_acc, frames=1, ao=0, what=""):
+    wins = _windows(base_acc, cfg.case.W, cfg.case.H)
+    for k, win in wins.items():
+        acc = cfg.oracle_frames(win, frames)
+        _check_crop(base_acc, acc, win, frames, ao, f"{what} {k} {win}")
+    return wins
+
+
+def test_c2_lanl_1024_dvr():
+    cfg = Config("c2_lanl", 1024)
+    try:
+        base = _properties(cfg)
+        _oracle_crops(cfg, base[1], what="C2")
+    finally:
+        cfg.close()
+
+
+def test_c3_gear_2048_dvr_two_channels_plus_iso():
+    cfg = Config("c3_gear", 2048, iso=[(0.5, 0)])
+    try:
+        assert cfg.R.params.numPrimaryChannels == 2
+        base = _properties(cfg)
+        _oracle_crops(cfg, base[1], what="C3")
+    finally:
+        cfg.close()
+
+
+@pytest.fixture(scope="module")
+def exajet_full():
+    """the bench scene (c4_exajet at scale 1.0: 6.4e8 cells), shared by C4 and C5"""
+    box = {}
+
+    def get(size, iso=None, ao=0):
+        if "cfg" not in box:
+            box["cfg"] = Config("c4_exajet", size, iso=iso, ao=ao)
+        cfg = box["cfg"]
+        if cfg.case.W != size or cfg.case.iso != iso or cfg.case.ao != ao:
+            S = cfg.S
+            case = Case(cfg.sc, W=size, H=size, grad=1, iso=iso, ao=ao, xf_domains=[(0.0, 1.0)])
+            R = cfg.R
+            lo, hi = R.voxelSpaceBounds
+            cam = case.cam(lo, hi)
+            R.resizeFrameBuffer((size, size))
+            R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
+            iso_v, iso_c, iso_e = [0.0, 0.0], [0, 0], [0, 0]
+            for i, spec in enumerate(iso or []):
+                iso_v[i], iso_c[i], iso_e[i] = spec[0], spec[1], 1
+            R.updateIsoValues(iso_v, iso_c, iso_e)
+            R.frameState.ao.enabled, R.frameState.ao.length = int(case.ao), float(case.ao_length)
+            cfg.case, cfg.S = case, S
+        return cfg
+    yield get
+    if "cfg" in box:
+        box["cfg"].close()
+
+
+def test_c4_exajet_full_2048_dvr(exajet_full):
+    cfg = exajet_full(2048)
+    assert cfg.sc.num_cells > 6e8
+    base = _properties(cfg)
+    _oracle_crops(cfg, base[1], what="C4")
+
+
+def test_c5_exajet_full_4096_dvr_iso_ao_16_frames(exajet_full):
+    cfg = exajet_full(4096, iso=[(0.5, 0)], ao=1)
+    # property checks on 2 accumulated frames (surfaces pre-pass + march, SURF variants of the kernels) ...
+    _properties(cfg, frames=2)
+    # ... and the 16-frame accumulation ("16 spp") against the oracle on both crops
+    cfg.R.setOption("tile_feedback", 1)
+    cfg.R.setOption("wide_march", 1)
+    base = cfg.render_frames(16)
+    _oracle_crops(cfg, base[1], frames=16, ao=1, what="C5")
+    # the iso-surface is really there: the frame differs from the DVR-only frame of C4's settings
+    cfg.R.updateIsoValues([0, 0], [0, 0], [0, 0])
+    plain = cfg.render_frames(1)
+    cfg.R.updateIsoValues([0.5, 0], [0, 0], [1, 0])
+    one = cfg.render_frames(1)
+    assert np.abs(plain[1] - one[1]).max() > 0.05

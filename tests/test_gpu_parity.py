@@ -7,13 +7,13 @@ import sys
 import numpy as np
 import pytest
 
-from common import ACCUM_ATOL, Case, ROOT, band_xf, compare, po
+from common import ACCUM_ATOL, FLIP_BOUND, Case, ROOT, band_xf, compare, po
 from owlexabrick_amd import binding, harness, scenes
 
 pytestmark = pytest.mark.gpu
 
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-from make_golden import GOLDEN_CASES, make_case  # noqa: E402
+from make_golden import GOLDEN_CASES, crop, golden_window, make_case  # noqa: E402
 
 STAT_KEYS = ["segments", "sample_evals", "samples", "brick_visits", "corner_loads", "iso_segments", "iso_evals"]
 
@@ -114,15 +114,57 @@ def test_shipped_kernel_equals_instrumented_variant(name, fast_math):
     assert np.array_equal(plain[0], counted[0])
 
 
-@pytest.mark.parametrize("name", ["ex3_grad", "c1_64", "amr_grad", "amr_band", "amr_2ch", "amr_inside", "gen_exajet"])
-def test_fast_math_default_within_stated_tolerance(name):
-    """the shipped default (hardware exp2/log2 opacity correction) against the oracle"""
+@pytest.mark.parametrize("accel", [1, 0], ids=["kd", "lbvh"])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_shipped_defaults_within_stated_tolerance(name, accel):
+    """every case of the matrix with the options a caller gets by default — fast_math=1 (hardware exp2/log2 opacity
+    correction, 1-ulp rcp/sqrt in the sample epilogue of the kd march; the LBVH variant has no fast path) and
+    tf_filter=1 — against the oracle, under the flip tolerance of tests/common.py"""
     case = CASES[name]()
+    case.accel = accel
     o, h = case.run_oracle(), case.run_hip(stats=True)
     r = compare(o, h, name)
+    if case.ao:      # AO directions go through cosf/sinf (libm vs OCML): a few rays may flip hit/miss
+        da = np.abs(o[1] - h[1]).max(axis=-1)
+        assert (da > FLIP_BOUND).sum() <= max(2, 0.003 * da.size), r
+        return
     assert r["flips_ok"] and r["rgba_bad"] <= 3 * r["flip_pixels"], r
     for k in ("samples", "brick_visits", "segments"):
         assert abs(o[2][k] - h[2][k]) <= 1e-3 * o[2][k] + 2, (k, o[2][k], h[2][k])
+
+
+def _step_tf(at=64):
+    xf = harness.default_xf()
+    xf[:, 3] = (np.arange(128) >= at).astype(np.float32) * 0.5
+    return xf
+
+
+@pytest.mark.parametrize("accel", [1, 0], ids=["kd", "lbvh"])
+def test_tf_filter_fixed_point_weight_matches_oracle_in_both_modes(accel):
+    """tf_filter 1 (default) = the CUDA tex1D filter weight in 1.8 fixed point, 0 = full precision: a two-texel ramp in
+    the opacity makes the weight itself visible; each mode equals the oracle in the same mode sample for sample, and
+    the two modes differ from each other"""
+    acc = {}
+    for mode in (1, 0):
+        case = Case(_amr(), W=96, H=96, grad=1, xf=_step_tf(40), tf_filter=mode, accel=accel, fast_math=0, opacity_scale=0.5)
+        o, h = case.run_oracle(), case.run_hip(stats=True)
+        r = compare(o, h, f"step tf, filter {mode}")
+        assert r["accum_bad"] == 0 and r["rgba_bad"] == 0, r
+        assert {k: o[2][k] for k in STAT_KEYS} == {k: h[2][k] for k in STAT_KEYS}
+        acc[mode] = h[1]
+    d = np.abs(acc[0] - acc[1])
+    assert d.max() > 1e-4            # the quantised weight is visible ...
+    assert d.max() < 0.05            # ... and small: at most 1/512 of a texel step per sample, plus rare termination flips
+    # activity of the regions goes through the same lookup (activeForVolumeSampling, exabrick.cu:250-281)
+    case = Case(_amr(), W=32, H=32, xf=_step_tf(40), accel=accel)
+    S = case.oracle_scene()
+    fs, P = case.oracle_state(S)
+    R = case.hip_renderer()
+    for mode in (1, 0):
+        R.setOption("tf_filter", mode)
+        S.set_tf_filter(mode)
+        assert np.array_equal(R.readActivity(0), S.volume_active(fs, P))
+    R.close()
 
 
 def test_ao_rays_match_up_to_trig_ulps():
@@ -141,11 +183,14 @@ def test_hip_matches_golden_fixture(name):
     case, frames = make_case(name)
     case.fast_math = 0
     rgba, acc, st = case.run_hip(frames=frames, stats=True)
+    win = golden_window(name)                        # the C1 fixtures hold a crop of the 512x512 frame
+    rgba, acc = np.ascontiguousarray(crop(rgba, win)), crop(acc, win)
     assert np.abs(acc - g["accum"]).max() <= ACCUM_ATOL
     d = np.abs(rgba.view(np.uint8).astype(int) - g["rgba"].view(np.uint8).astype(int))
     assert d.max() <= 1
-    gs = dict(zip([str(k) for k in g["stat_keys"]], g["stats"].tolist()))
-    assert {k: gs[k] for k in STAT_KEYS} == {k: st[k] for k in STAT_KEYS}
+    if win is None:                                  # the fixture's counters cover what the fixture holds
+        gs = dict(zip([str(k) for k in g["stat_keys"]], g["stats"].tolist()))
+        assert {k: gs[k] for k in STAT_KEYS} == {k: st[k] for k in STAT_KEYS}
 
 
 def test_region_activity_matches_bounds_programs():

@@ -43,6 +43,73 @@ def test_kat5_srgb_and_pack():
     assert L.or_make_rgba8(1.0, 0.5, 0.0) == (255 | (128 << 8) | (0 << 16) | (0xFF << 24))
 
 
+def _step_tf(at=64):
+    """a two-texel ramp: alpha 0 up to texel at-1, 1 from texel `at` on — between the two texel centres the
+    fetched alpha IS the filter weight"""
+    xf = harness.default_xf()
+    xf[:, 3] = (np.arange(128) >= at).astype(np.float32)
+    return xf
+
+
+def _lookup_sweep(tf_filter, n=4001):
+    sc = scenes.example("ex0")
+    S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    S.set_xf(0, _step_tf())
+    S.set_tf_filter(tf_filter)
+    fs = po.FrameState()
+    harness.fill_frame_state(fs, harness.default_camera([0, 0, 0], [1, 1, 1], 8, 8), [(0.0, 127.0)], xfOpacityScale=1.0)
+    # xfDomain [0,127]: lookupTransferFunction maps v to u = (v+.5)/127 and the fetch to x = 128u - .5
+    # (exabrick.cu:135-150); x runs over [63, 64] for v in about [62.49, 63.49]
+    vs = np.linspace(62.4, 63.6, n).astype(np.float32)
+    got = np.array([S.lookup_xf(fs, float(v))[3] for v in vs], dtype=np.float32)
+    x = ((np.clip(vs.astype(np.float64) + 0.5, 0, 127) / 127.0) * 128.0 - 0.5)
+    return vs, got, np.clip(x - 63.0, 0.0, 1.0)
+
+
+def test_tf_fetch_is_the_published_cuda_linear_filter():
+    """exabrick.cu:147 fetches the TF with tex1D<float4> (linear, clamp, normalized: exa/Texture.h:141-147).  The
+    CUDA C programming guide ("Texture Fetching", linear filtering) publishes tex(x) = (1-a)T[i] + aT[i+1] with
+    i = floor(x-.5), a = frac(x-.5), "a stored in 9-bit fixed point format with 8 bits of fractional value (so 1.0
+    is exactly represented)": on a two-texel ramp the fetched value takes exactly the 257 values k/256, each within
+    half a step of the unquantised weight."""
+    vs, got, exact = _lookup_sweep(1)
+    k = got.astype(np.float64) * 256.0
+    assert np.array_equal(k, np.round(k))                         # multiples of 1/256, exactly
+    assert got.min() == 0.0 and got.max() == 1.0                  # 0 and 1.0 are both represented
+    assert len(np.unique(got)) == 257
+    assert np.abs(got - exact).max() <= 0.5 / 256 + 2e-5          # nearest step (the f32 coordinate itself carries ~1e-5)
+    assert np.all(np.diff(got) >= 0)                              # monotone
+    # the full-precision option is the plain lerp: not quantised, within f32 rounding of the exact weight
+    vs0, got0, exact0 = _lookup_sweep(0)
+    assert np.abs(got0 - exact0).max() < 2e-5
+    inside = (exact0 > 0.01) & (exact0 < 0.99)
+    assert (np.abs(got0[inside] * 256 - np.round(got0[inside] * 256)) > 1e-3).mean() > 0.9
+    # and it is what the default does NOT do
+    assert np.abs(got - got0).max() > 0.4 / 256
+
+
+def test_tf_fetch_addressing_clamp_and_texel_centres():
+    """same fetch: texel i is centred at x = i + .5, i.e. the reference's lookup returns table entry i exactly for
+    value i of a [0,127] domain, and clamps at both ends (cudaAddressModeClamp)"""
+    sc = scenes.example("ex0")
+    S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    xf = harness.default_xf()
+    xf[:, 3] = np.linspace(0.1, 0.9, 128).astype(np.float32)
+    S.set_xf(0, xf)
+    fs = po.FrameState()
+    harness.fill_frame_state(fs, harness.default_camera([0, 0, 0], [1, 1, 1], 8, 8), [(0.0, 127.0)], xfOpacityScale=1.0)
+    for i in (0, 1, 17, 64, 126, 127):
+        # (i+.5)/127*128-.5 is i + (i+.5)/127: the lookup's normalisation by 127 instead of 128 shifts the fetch by up
+        # to one texel over the table — a property of the reference's arithmetic, kept
+        x = (i + 0.5) / 127.0 * 128.0 - 0.5
+        i0, a = int(np.floor(x)), x - np.floor(x)
+        a = np.round(a * 256) / 256
+        want = (1 - a) * xf[min(i0, 127), 3] + a * xf[min(i0 + 1, 127), 3]
+        assert abs(S.lookup_xf(fs, float(i))[3] - want) < 1e-6
+    assert S.lookup_xf(fs, -50.0)[3] == pytest.approx(S.lookup_xf(fs, -0.5)[3])       # clamp(scalar+.5, 0, 127)
+    assert S.lookup_xf(fs, 500.0)[3] == xf[127, 3]
+
+
 def test_box_test_semantics():
     # strict t0 < t1, true division, axis-parallel rays (dir component 0 -> +-inf, ignored by fmin/fmax)
     hit, t0, t1 = po.box_test([0, 0, -5], [0, 0, 1], 1e-6, 1e8, [-1, -1, -1], [1, 1, 1])
