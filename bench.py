@@ -155,13 +155,21 @@ def main():
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} HIP device(s) visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # EXA_BENCH_FORCE_DIST=1: a 1-rank job still goes through the process group, the gather and the stream pipeline
+    # (lets a one-GPU box run the RCCL calls of the N-rank path)
+    use_dist = world > 1 or bool(os.environ.get("EXA_BENCH_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    n_ranks_seen = dist.get_world_size() if use_dist else 1
     cdev = dev if backend == "nccl" else torch.device("cpu")     # where collectives operate
 
     W = H = args.size
@@ -223,21 +231,27 @@ def main():
     R.updateFrameID(0)
 
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    stride = ((tiles + world - 1) // world) * 256 if world > 1 else W * H
+    stride = ((tiles + world - 1) // world) * 256 if world > 1 else W * H      # a 1-rank "shard" is the row-major frame
     # Two shard buffers: while the shard of frame k travels to rank 0, frame k+1 is already being marched into the
     # other one (the accumulation buffer is not read at frameID 0, and with spp > 1 the gather waits for the last
     # sample anyway).  EXA_BENCH_PIPELINE=0 keeps every frame synchronous, like owlLaunch2D.
-    pipelined = world > 1 and backend == "nccl" and os.environ.get("EXA_BENCH_PIPELINE", "1") != "0"
+    pipelined = use_dist and backend == "nccl" and os.environ.get("EXA_BENCH_PIPELINE", "1") != "0"
     shards = [torch.zeros(stride, dtype=torch.int32, device=dev) for _ in range(2 if pipelined else 1)]
-    final = torch.zeros(W * H, dtype=torch.int32, device=dev) if (world > 1 and rank == 0) else None
+    final = torch.zeros(W * H, dtype=torch.int32, device=dev) if (use_dist and rank == 0) else None
     # rank 0 receives every shard straight into its slice of one flat buffer (no concatenation step)
-    gathered_flat = torch.zeros(stride * world, dtype=torch.int32, device=dev) if (world > 1 and rank == 0) else None
+    gathered_flat = torch.zeros(stride * world, dtype=torch.int32, device=dev) if (use_dist and rank == 0) else None
     gathered = list(gathered_flat.chunk(world)) if gathered_flat is not None else None
     render_stream = torch.cuda.Stream(device=dev) if pipelined else None
     comm_stream = torch.cuda.Stream(device=dev) if pipelined else None
     rendered = [torch.cuda.Event() for _ in shards]
     consumed = [torch.cuda.Event() for _ in shards]
     frame_no = [0]
+
+    def untile(stream_handle):
+        if world > 1:
+            R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=stream_handle)
+        else:
+            final.copy_(gathered_flat, non_blocking=True)             # forced 1-rank job: already row-major
 
     def step():
         k = frame_no[0] % len(shards)
@@ -249,7 +263,7 @@ def main():
                 if args.spp > 1:
                     R.updateFrameID(f)
                 R.render(device_ptr=shard.data_ptr(), stream=stream)       # synchronous, like owlLaunch2D
-            if world == 1:
+            if not use_dist:
                 return
             if backend == "nccl":
                 dist.gather(shard, gathered, dst=0)           # each peer -> root over its own xGMI link
@@ -260,7 +274,7 @@ def main():
                 if rank == 0:
                     gathered_flat.copy_(torch.cat(hl))
             if rank == 0:
-                R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=stream)
+                untile(stream)
             return
         # pipelined: the march goes to the render stream and returns at once; the gather + untile of this frame are
         # queued on the communication stream behind it and overlap the next frame's march
@@ -274,7 +288,7 @@ def main():
             comm_stream.wait_event(rendered[k])
             dist.gather(shard, gathered, dst=0)
             if rank == 0:
-                R.untile(gathered_flat.data_ptr(), stride, world, final.data_ptr(), stream=comm_stream.cuda_stream)
+                untile(comm_stream.cuda_stream)
             consumed[k].record(comm_stream)
 
     # work counters of this frame (instrumented kernel variant, frameID 0)
@@ -289,7 +303,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     kernel_ms = []
     t_start = time.perf_counter()
@@ -298,11 +312,11 @@ def main():
         if not pipelined:
             kernel_ms.append(R.stats()["kernel_ms"])       # the step's last launch
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
     if pipelined:
@@ -316,7 +330,7 @@ def main():
     agg = torch.tensor([st["samples"], st["brick_visits"], st["corner_loads"], st["segments"], st["nodes_visited"],
                         st["pixels"]], dtype=torch.float64, device=cdev)
     kmax = torch.tensor([float(np.mean(kernel_ms))], dtype=torch.float64, device=cdev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
         dist.all_reduce(kmax, op=dist.ReduceOp.MAX)
     samples_total = float(agg[0].item())
@@ -341,8 +355,8 @@ def main():
                                    f"gradient shading {'off' if args.no_grad else 'on'}, space skipping on, frameID 0",
                        "tiling": f"16x16 tiles interleaved over {world} GPU(s)"
                                  + (f", {'RCCL (nccl)' if backend == 'nccl' else backend} gather to rank 0"
-                                    f"{', overlapped with the next frame' if pipelined else ''}" if world > 1 else ""),
-                       "backend": backend if world > 1 else None,
+                                    f"{', overlapped with the next frame' if pipelined else ''}" if use_dist else ""),
+                       "backend": backend if use_dist else None,
                        "samples_per_frame": samples_total, "kernel_ms_max_over_ranks": float(kmax.item())},
             # Three views of the same launch: `achieved`/`frac` is SURVEY 8(d)'s formula — bytes the
             # lanes REQUEST (most are served by L1/L2) over kernel time, against the HBM peak; `hbm_measured` is what
@@ -382,7 +396,7 @@ def main():
         if "valu_issue" not in out["roofline"]:
             out["roofline"]["bound"] = "hbm"       # no counter file for this configuration: only the formula view
         if args.dump:
-            img = (final if world > 1 else shards[0]).cpu().numpy().view(np.uint32).reshape(H, W)
+            img = (final if use_dist else shards[0]).cpu().numpy().view(np.uint32).reshape(H, W)
             harness.write_png(args.dump, img)
 
         # ---------------- CPU baseline: the oracle on a bounded crop ----------------
@@ -432,7 +446,7 @@ def main():
                 "sample": f"{side1}x{side1} centre crop ({st_1['samples']} samples, {t_1:.1f}s on 1 thread), scaled by sample count"}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     R.close()

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libexa_hip.so")
+# EXA_HIP_LIB: another build of the same module (A/B timing of kernel variants, tools/ab_variants.sh)
+LIB_PATH = os.environ.get("EXA_HIP_LIB") or os.path.join(_HERE, "libexa_hip.so")
 
 NUM_XF_VALUES, MAX_CHANNELS, MAX_ISO, MAX_CONTOUR = 128, 10, 2, 3
 

@@ -50,7 +50,8 @@ static_assert(sizeof(RegionRec) == 48, "region record = three 16-byte loads");
 struct DeviceScene {
   const int4       *bricks;        // ExaBrick as two int4: (lower.xyz,size.x) (size.yz,level,begin)
   const int32_t    *leafList;
-  const int4       *leafHdr;       // brick records repeated along the leaf list (two int4 per entry)
+  const int4       *leafHdr;       // march headers along the leaf list, two int4 per entry:
+                                   // (float(lower.xyz), 2^-level | size.xyz, begin), see exa_module.cpp
   const float      *scalars;
   const RegionInfo *regionInfo;
   const float2     *valueRange;    // per region
@@ -99,6 +100,9 @@ struct RenderArgs {
   ExaHipFrameState   fs;
   ExaHipParams       p;
   const float4      *xf;            // numXfChannels x 128 (r,g,b,a)
+  int32_t            mul24;         // every brick: sizes < 2^24, size.x*size.y < 2^24, cells < 2^32 -> 24-bit multiplies
+  int32_t            addr32;        // a scalar field is below 4 GiB -> 32-bit byte offsets from a uniform base
+  float              invDtPow2;     // 1/dt when launch.dt is a power of two (exact), else 0
   float              tfFracMagic;   // 2^15: TF filter weight rounded to 8 fractional bits (CUDA tex1D), 0: full precision
   int32_t            numXfChannels;
   int32_t            W, H, tilesX, tilesY;

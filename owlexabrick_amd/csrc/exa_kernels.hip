@@ -9,6 +9,30 @@
 #include "exa_device.h"
 #include <cfloat>
 
+// Round-2 instruction trims of the kd march (profiles/r02_isa_budget.txt); each keeps every pixel bit for bit and can
+// be switched off at build time for A/B timing (-DEXA_OPT_...=0):
+//   POP1    one pop site in the kd step instead of five inlined copies
+//   ADDR32  cell loads as uniform base + 32-bit byte offset (global_load saddr form) when a field is < 4 GiB
+//   MUL24   24-bit integer multiplies in the cell address (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate)
+//   FHDR    march header carries float(lower) and 2^-level: no conversions / exponent build per visit; the -1 clamp
+//           of the cell index is done on the float
+//   DTPOW2  first sample of a segment: x / dt as x * (1/dt) when dt is a power of two (exact)
+#ifndef EXA_OPT_POP1
+#define EXA_OPT_POP1 1
+#endif
+#ifndef EXA_OPT_ADDR32
+#define EXA_OPT_ADDR32 1
+#endif
+#ifndef EXA_OPT_MUL24
+#define EXA_OPT_MUL24 1
+#endif
+#ifndef EXA_OPT_FHDR
+#define EXA_OPT_FHDR 1
+#endif
+#ifndef EXA_OPT_DTPOW2
+#define EXA_OPT_DTPOW2 1
+#endif
+
 namespace exa {
 
 // ------------------------------------------------------------------------
@@ -128,10 +152,12 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b)
 // ------------------------------------------------------------------------
 template <bool FAST = false>
 __device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameState &fs, float in_scalar, int channel,
-                                           const float fracMagic)
+                                           const float fracMagic, const float rcpRange = 0.f)
 {
+  // rcpRange != 0 (fast_math only): the caller's copy of rcp((hi - lo) + 1e-20f), the value fdiv<true> would compute here
   const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
-  float scalar = fdiv<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
+  float scalar = (FAST && rcpRange != 0.f) ? ((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo)) * rcpRange
+                                           : fdiv<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
   scalar = fminf(EXA_NUM_XF_VALUES - 1.f, fmaxf(0.f, scalar + .5f));
   scalar = fdiv<FAST>(scalar, EXA_NUM_XF_VALUES - 1.f);
   const float x = scalar * float(EXA_NUM_XF_VALUES) - 0.5f;
@@ -298,11 +324,28 @@ __device__ __forceinline__ Pair loadPair(const float *__restrict__ p) { return *
 // leaves a sum unchanged (the sums start at +0 and can never become -0), so the
 // accumulators see bit-identical values.  The speculative read of an out-of-brick corner
 // is clamped onto a cell that an in-brick corner of the same sample reads as well.
-template <bool DERIV, int STATS>
+template <bool DERIV, int STATS, bool SMALL>
 __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4 b0, const int4 b1,
                                              const float *__restrict__ field, V3 pos)
 {
+#if EXA_OPT_FHDR
+  // march header (exa_module: leafHdr): b0 = (float(lower.xyz), 2^-level) as float bits, b1 = (size.xyz, begin)
+  const int sx = b1.x, sy = b1.y, sz = b1.z;
+  const uint32_t begin = (uint32_t)b1.w;
+  const float invCw = __int_as_float(b0.w);                 // exact 2^-level: (p/cw) == p*invCw
+  const float lpx = (pos.x - __int_as_float(b0.x)) * invCw - 0.5f;
+  const float lpy = (pos.y - __int_as_float(b0.y)) * invCw - 0.5f;
+  const float lpz = (pos.z - __int_as_float(b0.z)) * invCw - 0.5f;
+  // idx_lo = max(-1, int(floor(local))) (exabrick.cu:627-629); the clamp on the float is the same value (floor is
+  // integral, -1 exact) and saves converting the clamped index back for the fraction
+  const float flx = fmaxf(floorf(lpx), -1.f), fly = fmaxf(floorf(lpy), -1.f), flz = fmaxf(floorf(lpz), -1.f);
+  const int lx = int(flx), ly = int(fly), lz = int(flz);
+  const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
+  const float fx = lpx - flx, fy = lpy - fly, fz = lpz - flz;
+#else
+  // b0 = (lower.xyz, size.x)  b1 = (size.y, size.z, level, begin): the ExaBrick record itself
   const int sx = b0.w, sy = b1.x, sz = b1.y;
+  const uint32_t begin = (uint32_t)b1.w;
   const float invCw = __int_as_float((127 - b1.z) << 23);   // exact 2^-level
   const float lpx = (pos.x - float(b0.x)) * invCw - 0.5f;
   const float lpy = (pos.y - float(b0.y)) * invCw - 0.5f;
@@ -310,22 +353,41 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const int lx = max(-1, int(floorf(lpx))), ly = max(-1, int(floorf(lpy))), lz = max(-1, int(floorf(lpz)));
   const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
   const float fx = lpx - float(lx), fy = lpy - float(ly), fz = lpz - float(lz);
+#endif
   const bool vlx = lx >= 0 && lx < sx, vhx = hx < sx;
   const bool vly = ly >= 0 && ly < sy, vhy = hy < sy;
   const bool vlz = lz >= 0 && lz < sz, vhz = hz < sz;
   const int cxl = min(max(lx, 0), sx - 1), cxh = min(hx, sx - 1);
   const int cyl = min(max(ly, 0), sy - 1), cyh = min(hy, sy - 1);
   const int czl = min(max(lz, 0), sz - 1), czh = min(hz, sz - 1);
-  const uint32_t sxy = (uint32_t)(sx * sy);
-  const uint32_t zl = (uint32_t)b1.w + (uint32_t)czl * sxy, zh = (uint32_t)b1.w + (uint32_t)czh * sxy;
-  const uint32_t yl = (uint32_t)(cyl * sx), yh = (uint32_t)(cyh * sx);
-  const uint32_t rowLL = zl + yl, rowHL = zl + yh, rowLH = zh + yl, rowHH = zh + yh;
+  const int bx = min(max(lx, 0), max(sx - 2, 0));
+  uint32_t rowLL, rowHL, rowLH, rowHH;                      // cell index of the pair's first cell, per (y,z) row
+  if (EXA_OPT_MUL24 && SMALL) {
+    // SMALL: every factor below 2^24 and every product below 2^32 (checked per scene on the host)
+    const uint32_t sxy = __umul24((uint32_t)sx, (uint32_t)sy);
+    const uint32_t zl = __umul24((uint32_t)czl, sxy) + (begin + (uint32_t)bx);
+    const uint32_t zh = __umul24((uint32_t)czh, sxy) + (begin + (uint32_t)bx);
+    const uint32_t yl = __umul24((uint32_t)cyl, (uint32_t)sx), yh = __umul24((uint32_t)cyh, (uint32_t)sx);
+    rowLL = zl + yl; rowHL = zl + yh; rowLH = zh + yl; rowHH = zh + yh;
+  } else {
+    const uint32_t sxy = (uint32_t)(sx * sy);
+    const uint32_t zl = begin + (uint32_t)czl * sxy + (uint32_t)bx, zh = begin + (uint32_t)czh * sxy + (uint32_t)bx;
+    const uint32_t yl = (uint32_t)(cyl * sx), yh = (uint32_t)(cyh * sx);
+    rowLL = zl + yl; rowHL = zl + yh; rowLH = zh + yl; rowHH = zh + yh;
+  }
   // the two x-neighbours of a row are adjacent in memory: one 8-byte load per row (4-byte
   // aligned), then pick the clamped low/high cell out of the pair
-  const int bx = min(max(lx, 0), max(sx - 2, 0));
   const bool lFirst = cxl == bx, hFirst = cxh == bx;
-  const Pair pLL = loadPair(field + rowLL + bx), pHL = loadPair(field + rowHL + bx);
-  const Pair pLH = loadPair(field + rowLH + bx), pHH = loadPair(field + rowHH + bx);
+  Pair pLL, pHL, pLH, pHH;
+  if (EXA_OPT_ADDR32 && SMALL) {
+    // SMALL: a field is below 4 GiB: wave-uniform base + 32-bit byte offset per lane (no 64-bit address arithmetic)
+    const char *base = reinterpret_cast<const char *>(field);
+    pLL = *reinterpret_cast<const Pair *>(base + (rowLL << 2)); pHL = *reinterpret_cast<const Pair *>(base + (rowHL << 2));
+    pLH = *reinterpret_cast<const Pair *>(base + (rowLH << 2)); pHH = *reinterpret_cast<const Pair *>(base + (rowHH << 2));
+  } else {
+    pLL = loadPair(field + rowLL); pHL = loadPair(field + rowHL);
+    pLH = loadPair(field + rowLH); pHH = loadPair(field + rowHH);
+  }
   const float s000 = lFirst ? pLL.a : pLL.b, s100 = hFirst ? pLL.a : pLL.b;
   const float s010 = lFirst ? pHL.a : pHL.b, s110 = hFirst ? pHL.a : pHL.b;
   const float s001 = lFirst ? pLH.a : pLH.b, s101 = hFirst ? pLH.a : pLH.b;
@@ -398,9 +460,9 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
 // the sample's colour after gradient shading and its opacity after the correction; actual_dt != 0
 template <bool FAST, int STATS>
 __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, float actual_dt, float cellValue, V3 gradient,
-                                              int finestLevelCellWidth, int channel)
+                                              int finestLevelCellWidth, int channel, const float rcpRange = 0.f)
 {
-  Color4 sample = lookupXF<FAST>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic);
+  Color4 sample = lookupXF<FAST>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic, rcpRange);
   if (fsqrt<FAST>(dot(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
     const float scale = fdiv<FAST>(fabsf(dot(lightDir, gradient)), fsqrt<FAST>(dot(gradient, gradient) * dot(lightDir, lightDir)));
@@ -427,10 +489,11 @@ __device__ __forceinline__ void compositeSample(Color4 &pixelColor, const Color4
 // exabrick.cu:988-1016 integrateVolume
 template <bool FAST, int STATS>
 __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
-                                                float cellValue, V3 gradient, int finestLevelCellWidth, int channel)
+                                                float cellValue, V3 gradient, int finestLevelCellWidth, int channel,
+                                                const float rcpRange = 0.f)
 {
   if (actual_dt == 0.f) return;
-  const Color4 sample = shadeSample<FAST>(C, ray, actual_dt, cellValue, gradient, finestLevelCellWidth, channel);
+  const Color4 sample = shadeSample<FAST>(C, ray, actual_dt, cellValue, gradient, finestLevelCellWidth, channel, rcpRange);
   compositeSample(pixelColor, sample);
 }
 
@@ -443,6 +506,18 @@ __device__ __forceinline__ float firstSampleT(float t0, float dt, float off)
   const int i0 = int(ceilf((t0 - dt * off) / dt));
   float t_i = (off + i0) * dt;
   for (int g = 0; g < 64 && (t_i - dt) >= t0; g++) t_i = t_i - dt;
+  for (int g = 0; g < 64 && t_i < t0; g++) t_i += dt;
+  return t_i;
+}
+// the same with x / dt as x * invDt, for a step that is a power of two (invDt = 1/dt exactly, so quotient and product
+// are the same real number and round alike); the two correction loops almost never run and stay rolled
+__device__ __forceinline__ float firstSampleTPow2(float t0, float dt, float invDt, float off)
+{
+  const int i0 = int(ceilf((t0 - dt * off) * invDt));
+  float t_i = (off + i0) * dt;
+#pragma unroll 1
+  for (int g = 0; g < 64 && (t_i - dt) >= t0; g++) t_i = t_i - dt;
+#pragma unroll 1
   for (int g = 0; g < 64 && t_i < t0; g++) t_i += dt;
   return t_i;
 }
@@ -1151,6 +1226,14 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     w.ref = EXA_KD_EMPTY;
   }
   if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop(C, w, root, stackF);
+  // With EXA_OPT_POP1 this is the only pop: a node that leaves nothing to descend into marks the subtree EMPTY and
+  // the pop happens here at the start of the lane's next call, in front of that call's node stage — the same
+  // sequence of subtrees, with one inlined copy of the pop instead of five for the wave's divergent lanes to run
+#if EXA_OPT_POP1
+#define EXA_KD_POP_LATER() (w.ref = EXA_KD_EMPTY)
+#else
+#define EXA_KD_POP_LATER() kdPop(C, w, root, stackF)
+#endif
   // the popped subtree gets its own look at tmin / tmax in the next call
   if (w.ref < 0 || !(w.tf > walkTmin) || (ISOWALK && !(w.tn < walkTmax))) return;
   const int4 n = *reinterpret_cast<const int4 *>(nodes + w.ref);
@@ -1170,7 +1253,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     // (boxTest turns lo==o / hi==o into a miss, exabrick.cu:201-208 with NaN-ignoring min/max)
     if (o < split && (bits & 1)) w.ref = n.z;
     else if (o > split && (bits & 2)) w.ref = n.w;
-    else kdPop(C, w, root, stackF);
+    else EXA_KD_POP_LATER();
     return;
   }
   const float ts = (split - o) / d;                         // same expression as the slab test
@@ -1178,9 +1261,9 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
   const int nearRef = nearIsLeft ? n.z : n.w, farRef = nearIsLeft ? n.w : n.z;
   const bool nearAct = (bits & (nearIsLeft ? 1 : 2)) != 0, farAct = (bits & (nearIsLeft ? 2 : 1)) != 0;
   if (ts >= w.tf) {                                          // plane behind the interval: near side only
-    if (nearAct) w.ref = nearRef; else kdPop(C, w, root, stackF);
+    if (nearAct) w.ref = nearRef; else EXA_KD_POP_LATER();
   } else if (ts <= w.tn) {                                   // plane before the interval: far side only
-    if (farAct) w.ref = farRef; else kdPop(C, w, root, stackF);
+    if (farAct) w.ref = farRef; else EXA_KD_POP_LATER();
   } else if (nearAct) {
     if (farAct) {                                            // push far [ts,tf], go near [tn,ts]
       const int head = w.pk.get(PK_SHEAD), count = w.pk.get(PK_SCOUNT);
@@ -1196,9 +1279,10 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     w.ref = farRef;
     w.tn = ts;
   } else {
-    kdPop(C, w, root, stackF);
+    EXA_KD_POP_LATER();
   }
 }
+#undef EXA_KD_POP_LATER
 
 // exabrick.cu:1408-1460 traceIsoRay on the kd walk (iso activity bits): segments come out of the
 // ordered walk, one lane at a time refills its own queue here (the iso pre-pass is not the
@@ -1425,7 +1509,7 @@ __global__ __launch_bounds__(kKdBlock, 3) void surfacePrepassKdKernel(const Rend
   }
 }
 
-template <bool GRAD, bool FAST, bool MULTI, bool SURF, int STATS>
+template <bool GRAD, bool FAST, bool MULTI, bool SURF, int STATS, bool SMALL>
 __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1477,12 +1561,12 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     ray.dir = normalize((mk(fs.cam_dir00) + sx * mk(fs.cam_dirDu)) + sy * mk(fs.cam_dirDv));
     ray.tmin = 1e-6f; ray.tmax = 1e8f;
     // ---- surfaces: results of the pre-pass launch (the background colour is fetched after the march) ----
-    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
-                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
     float surface_t_hit = ray.tmax;
     if (SURF) {
-      surface_t_hit = a.surf[slot].w;
-      rnd.state = a.surfRnd[slot];
+      const size_t slot0 = (a.world == 1) ? size_t(px) + size_t(a.W) * py
+                                          : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+      surface_t_hit = a.surf[slot0].w;
+      rnd.state = a.surfRnd[slot0];
     }
     const float interleavedSamplingOffset = rnd.next();                           // :1655
     ray.tmax = surface_t_hit;                                                     // :1657-1659
@@ -1521,13 +1605,19 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     bool haveSeg = false;
     int listBegin = 0, listSize = 0;
     float flcw = 1.f;                     // region.finestLevelCellWidth; dt = launch.dt * flcw (:1129)
-    float t1 = 0.f, t_i = 0.f, t_last = 0.f, t_sample = 0.f, actual_dt = 0.f;
+    float t1 = 0.f, t_i = 0.f, t_sample = 0.f, actual_dt = 0.f;   // this step's t_next is fminf(t_i, t1): not kept
     int child = 0, chan = 0;                                     // chan stays 0 (and folds away) unless MULTI
-    int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 0, 0);
+    int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 1, 0);
     Basis B;
     B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
     const float *field0 = a.sc.scalars + a.sc.channelOffset[0];   // wave-uniform
     const float *field = field0;
+    // fast_math, one channel: the reciprocal of the TF range is the same for every sample of the frame; it is
+    // wave-uniform, so it lives in a scalar register (readfirstlane) instead of a vector register
+    float xfRcpRange0 = 0.f;
+    if (FAST && !MULTI)
+      xfRcpRange0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
+                        __builtin_amdgcn_rcpf((fs.xfDomain[0][1] - fs.xfDomain[0][0]) + 1e-20f))));
 
     unsigned iter = 0;
     for (;; iter++) {
@@ -1568,13 +1658,15 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         C.count(ST_SEGMENTS);
         haveSeg = true;
         w.pk.set(PK_NEEDHDR, 1);
-        t_i = firstSampleT(t0, a.p.dt * flcw, interleavedSamplingOffset);          // :1141-1144
+        if (EXA_OPT_DTPOW2 && a.invDtPow2 != 0.f)                                   // :1141-1144
+          t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float(0x7f000000 - __float_as_int(flcw)), interleavedSamplingOffset);
+        else
+          t_i = firstSampleT(t0, a.p.dt * flcw, interleavedSamplingOffset);
         // first step of the segment (:1158-1166)
         {
           const float t_next = fminf(t_i, t1);
           t_sample = 0.5f * (fminf(t1, t_next) + t0);
           actual_dt = t_next - t0;
-          t_last = t_next;
         }
         // child, chan/field and the basis sums are already at their start values here: the sample
         // epilogue resets them, and a segment only ends there
@@ -1591,7 +1683,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
         w.pk.set(PK_NEEDHDR, 0);
       }
-      addBasisFast<GRAD, STATS>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
+      addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
       child++;
       if (child < listSize) continue;
 
@@ -1605,7 +1697,8 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
                             B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
-        integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, (int)flcw, MULTI ? chan : 0);
+        integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, (int)flcw, MULTI ? chan : 0,
+                              (FAST && !MULTI) ? xfRcpRange0 : 0.f);
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0;
@@ -1626,7 +1719,8 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         pixelColor.w = 1.f;
         break;
       }
-      if (t_last >= t1) {                        // t_last holds this step's t_next: segment done (:1182; :1698 is in kdStep)
+      const float t_last = fminf(t_i, t1);       // this step's t_next (:1158), recomputed instead of kept in a register
+      if (t_last >= t1) {                        // segment done (:1182; :1698 is in kdStep)
         haveSeg = false;
         continue;
       }
@@ -1635,13 +1729,24 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         const float t_next = fminf(t_i, t1);
         t_sample = 0.5f * (fminf(t1, t_next) + t_last);
         actual_dt = t_next - t_last;
-        t_last = t_next;
       }
       C.count(ST_SAMPLE_EVALS);
     }
 
     C.lap(ST_T_OTHER);
     marchIters = iter;
+    // The pixel's framebuffer slot is worked out again from the thread id instead of being kept in two registers
+    // across the march (the kernel runs at exactly 80 VGPRs; the asm keeps the compiler from re-using the value
+    // computed before the loop).
+    size_t slot;
+    {
+      unsigned tid = threadIdx.x;
+      asm volatile("" : "+v"(tid));
+      const int lane2 = tid & 63, wave2 = (tid >> 6) & 3;
+      const int inX2 = ((wave2 & 1) << 3) + (lane2 & 7), inY2 = ((wave2 >> 1) << 3) + (lane2 >> 3);
+      slot = (a.world == 1) ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2)
+                            : size_t(tile / a.world) * kTilePixels + (inY2 * kTile + inX2);
+    }
     float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
     if (SURF) bgColor = a.surf[slot];
     float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
@@ -1706,6 +1811,11 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
     w.ref = EXA_KD_EMPTY;
   }
   if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > winLo))) kdPop(C, w, root, stackF);
+#if EXA_OPT_POP1
+#define EXA_KD_POP_LATER() (w.ref = EXA_KD_EMPTY)
+#else
+#define EXA_KD_POP_LATER() kdPop(C, w, root, stackF)
+#endif
   if (w.ref < 0 || !(w.tf > winLo) || !(w.tn < winHi)) return;
   const int4 n = *reinterpret_cast<const int4 *>(nodes + w.ref);
   const float split = __int_as_float(n.x);
@@ -1718,7 +1828,7 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
   if (d == 0.f) {
     if (o < split && (bits & 1)) w.ref = n.z;
     else if (o > split && (bits & 2)) w.ref = n.w;
-    else kdPop(C, w, root, stackF);
+    else EXA_KD_POP_LATER();
     return;
   }
   const float ts = (split - o) / d;
@@ -1726,9 +1836,9 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
   const int nearRef = nearIsLeft ? n.z : n.w, farRef = nearIsLeft ? n.w : n.z;
   const bool nearAct = (bits & (nearIsLeft ? 1 : 2)) != 0, farAct = (bits & (nearIsLeft ? 2 : 1)) != 0;
   if (ts >= w.tf) {
-    if (nearAct) w.ref = nearRef; else kdPop(C, w, root, stackF);
+    if (nearAct) w.ref = nearRef; else EXA_KD_POP_LATER();
   } else if (ts <= w.tn) {
-    if (farAct) w.ref = farRef; else kdPop(C, w, root, stackF);
+    if (farAct) w.ref = farRef; else EXA_KD_POP_LATER();
   } else if (nearAct) {
     if (farAct) {
       const int head = w.pk.get(PK_SHEAD), count_ = w.pk.get(PK_SCOUNT);
@@ -1744,11 +1854,12 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
     w.ref = farRef;
     w.tn = ts;
   } else {
-    kdPop(C, w, root, stackF);
+    EXA_KD_POP_LATER();
   }
 }
+#undef EXA_KD_POP_LATER
 
-template <bool GRAD, bool FAST, bool SURF, int L>
+template <bool GRAD, bool FAST, bool SURF, int L, bool SMALL>
 __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1858,7 +1969,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
     float t1 = 0.f, tiBase = 0.f, tlBase = 0.f;        // t_i of the step's first sample, t_next of the sample before it
     float t_sample = 0.f, actual_dt = 0.f;
     int child = 0;
-    int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 0, 0);
+    int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 1, 0);
     Basis B;
     B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
     const float *field0 = a.sc.scalars + a.sc.channelOffset[0];
@@ -1947,7 +2058,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
           const unsigned at = 2u * (unsigned)(listBegin + child);
           hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
         }
-        addBasisFast<GRAD, false>(C, B, hb0, hb1, field0, ray.org + t_sample * ray.dir);   // :1166
+        addBasisFast<GRAD, 0, SMALL>(C, B, hb0, hb1, field0, ray.org + t_sample * ray.dir);   // :1166
         myVisits++;
       }
       needHdr = false;
@@ -2033,11 +2144,14 @@ hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay
   if (numTiles <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numTiles * lanesPerRay), block(kKdBlock);
-#define EXA_W3(G, F, S) do { if (lanesPerRay == 2) hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, 2>), grid, block, lds, s, a); \
-                             else hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, 4>), grid, block, lds, s, a); } while (0)
+  const bool small = a.mul24 && a.addr32;                   // 24-bit address multiplies and 32-bit byte offsets are valid
+#define EXA_W4(G, F, S, L) do { if (small) hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, L, true>), grid, block, lds, s, a); \
+                                else hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, L, false>), grid, block, lds, s, a); } while (0)
+#define EXA_W3(G, F, S) do { if (lanesPerRay == 2) EXA_W4(G, F, S, 2); else EXA_W4(G, F, S, 4); } while (0)
 #define EXA_W2(G, F) do { if (surf) EXA_W3(G, F, true); else EXA_W3(G, F, false); } while (0)
   if (grad) { if (fast) EXA_W2(true, true); else EXA_W2(true, false); }
   else      { if (fast) EXA_W2(false, true); else EXA_W2(false, false); }
+#undef EXA_W4
 #undef EXA_W2
 #undef EXA_W3
   return hipGetLastError();
@@ -2060,8 +2174,11 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   const bool multi = a.p.numPrimaryChannels > 1;
-#define EXA_LAUNCH(G, F, M, I, S) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S>), grid, block, lds, s, a)
-#define EXA_PICK2(G, F, M, I) do { if (stats == 1) EXA_LAUNCH(G, F, M, I, 1); else if (stats == 2) EXA_LAUNCH(G, F, M, I, 2); else EXA_LAUNCH(G, F, M, I, 0); } while (0)
+  // the instrumented variants keep the general address arithmetic (fewer instantiations)
+  const bool small = a.mul24 && a.addr32;
+#define EXA_LAUNCH(G, F, M, I, S, A) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S, A>), grid, block, lds, s, a)
+#define EXA_PICK2(G, F, M, I) do { if (stats == 1) EXA_LAUNCH(G, F, M, I, 1, false); else if (stats == 2) EXA_LAUNCH(G, F, M, I, 2, false); \
+                                   else if (small) EXA_LAUNCH(G, F, M, I, 0, true); else EXA_LAUNCH(G, F, M, I, 0, false); } while (0)
 #define EXA_PICK(G, F, M) do { if (surf) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
   if (grad) {
     if (fast) { if (multi) EXA_PICK(true, true, true); else EXA_PICK(true, true, false); }

@@ -247,6 +247,7 @@ struct ExaHipRenderer {
   int tileOrder = 4;                 // Z-order launch sequence (measured best on C4)
   int debugPixel = -1;
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
+  int mul24 = 0, addr32 = 0;         // address arithmetic the scene's sizes allow (set at creation)
   int tfFilter = 1;                  // TF filter weight in 1.8 fixed point as CUDA's tex1D (0: full precision)
   float tfFracMagic() const { return tfFilter ? 32768.f : 0.f; }
   DevBuf<float4> accum;
@@ -638,6 +639,13 @@ struct ExaHipRenderer {
     a.p = p;
     a.xf = xf.p;
     a.tfFracMagic = tfFracMagic();
+    a.mul24 = mul24; a.addr32 = addr32;
+    {
+      // launch.dt a power of two (the reference's default 0.5 is): 1/dt is exact and x/dt == x*(1/dt)
+      int e = 0;
+      const float mant = std::frexp(p.dt, &e);
+      a.invDtPow2 = (mant == 0.5f && e > -100 && e < 100) ? 1.f / p.dt : 0.f;
+    }
     a.numXfChannels = numFields;
     a.W = W; a.H = H; a.tilesX = tilesX; a.tilesY = tilesY;
     a.rank = rank; a.world = world;
@@ -767,10 +775,38 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   CREATE_TRY(h->bricks.upload(reinterpret_cast<const int4 *>(scene->bricks), scene->numBricks * 2));
   CREATE_TRY(h->leafList.upload(scene->leafList, scene->leafListSize));
   {
+    // march headers along the leaf list (the kd march reads the record at listBegin + child, no id indirection).
+    // EXA_OPT_FHDR: what a brick visit needs, ready to use — float(lower) (the conversion the reference's
+    // `vec3f(brick.lower)` performs, exabrick.cu:623), 2^-level, the sizes and the first cell's offset
+#ifndef EXA_OPT_FHDR
+#define EXA_OPT_FHDR 1
+#endif
     std::vector<ExaBrick> hdr(scene->leafListSize);
-    for (uint64_t i = 0; i < scene->leafListSize; i++) hdr[i] = scene->bricks[scene->leafList[i]];
+    for (uint64_t i = 0; i < scene->leafListSize; i++) {
+      const ExaBrick &B = scene->bricks[scene->leafList[i]];
+#if EXA_OPT_FHDR
+      const float lowerF[3] = { float(B.lower[0]), float(B.lower[1]), float(B.lower[2]) };
+      const float invCw = std::ldexp(1.f, -B.level);
+      ExaBrick &o = hdr[i];
+      std::memcpy(&o.lower[0], lowerF, sizeof(lowerF));
+      std::memcpy(&o.size[0], &invCw, sizeof(float));
+      o.size[1] = B.size[0]; o.size[2] = B.size[1]; o.level = B.size[2]; o.begin = B.begin;
+#else
+      hdr[i] = B;
+#endif
+    }
     CREATE_TRY(h->leafHdr.upload(reinterpret_cast<const int4 *>(hdr.data()), hdr.size() * 2));
   }
+  // 24-bit multiplies in the cell address need every factor below 2^24 and every product below 2^32; 32-bit byte
+  // offsets need a field below 4 GiB (the pair load reads one float past a row's last cell at most)
+  h->mul24 = 1;
+  for (uint64_t b = 0; b < scene->numBricks; b++) {
+    const ExaBrick &B = scene->bricks[b];
+    if (uint64_t(B.size[0]) * uint64_t(B.size[1]) >= (1ull << 24) || B.size[0] >= (1 << 24) || B.size[1] >= (1 << 24) || B.size[2] >= (1 << 24))
+      h->mul24 = 0;
+  }
+  if (scene->totalCells >= (1ull << 32)) h->mul24 = 0;
+  h->addr32 = (scene->totalCells + 2) * sizeof(float) <= (1ull << 32) ? 1 : 0;
   CREATE_TRY(h->scalars.upload(scene->scalars, size_t(scene->numFields) * scene->totalCells));
   std::vector<RegionInfo> ri(scene->numRegions);
   std::vector<float2> vr(scene->numRegions);

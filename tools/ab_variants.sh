@@ -1,0 +1,39 @@
+#!/bin/bash
+# Builds libexa_hip variants with different -DEXA_OPT_* switches (here, no GPU needed) into build/variants/ (git-ignored,
+# travels to the GPU box), and on the GPU box times each with bench.py on C4, twice, interleaved.
+#   tools/ab_variants.sh build  name1:"-DEXA_OPT_X=0 ..." name2:"..."
+#   tools/ab_variants.sh run [bench args]      -> gpurun_out/variants/results.txt
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+LIBS="$ROOT/build/variants"
+OUT="$ROOT/gpurun_out/variants"
+CS="$ROOT/owlexabrick_amd/csrc"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function"
+mode=$1; shift
+if [ "$mode" = build ]; then
+  mkdir -p "$OUT" "$LIBS"
+  for spec in "$@"; do
+    name=${spec%%:*}; defs=${spec#*:}
+    (
+      d="$OUT/obj_$name"; mkdir -p "$d"
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c "$CS/exa_kernels.hip" -o "$d/exa_kernels.o" &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -x hip -c "$CS/exa_module.cpp" -o "$d/exa_module.o" &&
+      /opt/rocm/bin/hipcc $FLAGS -c "$CS/exa_prep.cpp" -o "$d/exa_prep.o" &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$LIBS/libexa_hip_$name.so" "$d"/*.o -lpthread &&
+      rm -rf "$d" && echo "built $name ($defs)"
+    ) 2>"$OUT/build_$name.err" &
+  done
+  wait
+  ls -la "$LIBS"/*.so
+else
+  mkdir -p "$OUT"
+  : > "$OUT/results.txt"
+  for rep in 1 2; do
+    for so in "$LIBS"/libexa_hip_*.so; do
+      name=$(basename "$so" .so); name=${name#libexa_hip_}
+      EXA_HIP_LIB="$so" timeout -k 10 120 python3 "$ROOT/bench.py" --cpu-baseline off --steps 20 --warmup 3 "$@" > "$OUT/$name.$rep.json" 2> "$OUT/$name.$rep.err" \
+        && python3 -c "import json,sys; d=json.loads(open('$OUT/$name.$rep.json').read().strip().splitlines()[-1]); print('%-12s rep $rep  %.3f ms/frame  kernel %.3f ms  %.2f fps' % ('$name', d['ms_per_step'], d['roofline']['kernel_ms'], d['value']))" | tee -a "$OUT/results.txt" \
+        || { echo "$name failed" | tee -a "$OUT/results.txt"; tail -3 "$OUT/$name.$rep.err"; }
+    done
+  done
+fi
