@@ -101,7 +101,8 @@ struct RenderArgs {
   ExaHipParams       p;
   const float4      *xf;            // numXfChannels x 128 (r,g,b,a)
   int32_t            mul24;         // every brick: sizes < 2^24, size.x*size.y < 2^24, cells < 2^32 -> 24-bit multiplies
-  int32_t            addr32;        // a scalar field is below 4 GiB -> 32-bit byte offsets from a uniform base
+  int32_t            addr32;        // a scalar field, the march headers and the kd nodes are each below 4 GiB ->
+                                    // 32-bit byte offsets from a uniform base
   float              invDtPow2;     // 1/dt when launch.dt is a power of two (exact), else 0
   float              tfFracMagic;   // 2^15: TF filter weight rounded to 8 fractional bits (CUDA tex1D), 0: full precision
   int32_t            numXfChannels;

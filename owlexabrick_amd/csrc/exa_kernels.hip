@@ -150,14 +150,14 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b)
 // fracMagic = 2^15 rounds a to the nearest 1/256 (a float in [2^15, 2^16) has exactly 8 fractional
 // bits), fracMagic = 0 keeps the full-precision weight (option tf_filter).
 // ------------------------------------------------------------------------
-template <bool FAST = false>
+template <bool FAST = false, bool HAVE_RCP = false>
 __device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameState &fs, float in_scalar, int channel,
                                            const float fracMagic, const float rcpRange = 0.f)
 {
-  // rcpRange != 0 (fast_math only): the caller's copy of rcp((hi - lo) + 1e-20f), the value fdiv<true> would compute here
+  // HAVE_RCP (fast_math only): rcpRange is the caller's copy of rcp((hi - lo) + 1e-20f), the value fdiv<true> computes here
   const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
-  float scalar = (FAST && rcpRange != 0.f) ? ((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo)) * rcpRange
-                                           : fdiv<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
+  float scalar = (FAST && HAVE_RCP) ? ((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo)) * rcpRange
+                                    : fdiv<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
   scalar = fminf(EXA_NUM_XF_VALUES - 1.f, fmaxf(0.f, scalar + .5f));
   scalar = fdiv<FAST>(scalar, EXA_NUM_XF_VALUES - 1.f);
   const float x = scalar * float(EXA_NUM_XF_VALUES) - 0.5f;
@@ -354,9 +354,10 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
   const float fx = lpx - float(lx), fy = lpy - float(ly), fz = lpz - float(lz);
 #endif
-  const bool vlx = lx >= 0 && lx < sx, vhx = hx < sx;
-  const bool vly = ly >= 0 && ly < sy, vhy = hy < sy;
-  const bool vlz = lz >= 0 && lz < sz, vhz = hz < sz;
+  // 0 <= l < size as one unsigned compare (l >= -1, sizes > 0)
+  const bool vlx = (uint32_t)lx < (uint32_t)sx, vhx = hx < sx;
+  const bool vly = (uint32_t)ly < (uint32_t)sy, vhy = hy < sy;
+  const bool vlz = (uint32_t)lz < (uint32_t)sz, vhz = hz < sz;
   const int cxl = min(max(lx, 0), sx - 1), cxh = min(hx, sx - 1);
   const int cyl = min(max(ly, 0), sy - 1), cyh = min(hy, sy - 1);
   const int czl = min(max(lz, 0), sz - 1), czh = min(hz, sz - 1);
@@ -407,11 +408,19 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
     const float mzl = vlz ? -1.f : 0.f, mzh = vhz ? 1.f : 0.f;
     const float zxLL = wzl * wxl, zxLH = wzl * wxh, zxHL = wzh * wxl, zxHH = wzh * wxh;   // [z][x]
     const float yxLL = wyl * wxl, yxLH = wyl * wxh, yxHL = wyh * wxl, yxHH = wyh * wxh;   // [y][x]
+    // The derivative weight of a corner is +-(product of the other two axes' weights) or 0: dx_ = zy * mx with
+    // mx in {-1, 0, +1}, an EXACT product.  So `sum += dx_` is one fused multiply-add with the same result bit for
+    // bit (an fma rounds once, and there is nothing to round in zy * mx), and `sum += dx_ * s` equals
+    // fma(zy * s, mx, sum): (+-zy) * s rounds to +-(zy * s), and for mx = 0 both forms add a zero of the sign of s.
+    // 13 instructions per corner instead of 16.
 #define EXA_ACC(S, ZY, WX, MX, ZX, MY, YX, MZ)                                               \
     {                                                                                        \
-      const float dx_ = (ZY) * (MX), dy_ = (ZX) * (MY), dz_ = (YX) * (MZ);                   \
-      B.sumDC.x += dx_; B.sumDC.y += dy_; B.sumDC.z += dz_;                                  \
-      B.sumD.x += dx_ * (S); B.sumD.y += dy_ * (S); B.sumD.z += dz_ * (S);                   \
+      B.sumDC.x = __builtin_fmaf((ZY), (MX), B.sumDC.x);                                     \
+      B.sumDC.y = __builtin_fmaf((ZX), (MY), B.sumDC.y);                                     \
+      B.sumDC.z = __builtin_fmaf((YX), (MZ), B.sumDC.z);                                     \
+      B.sumD.x = __builtin_fmaf((ZY) * (S), (MX), B.sumD.x);                                 \
+      B.sumD.y = __builtin_fmaf((ZX) * (S), (MY), B.sumD.y);                                 \
+      B.sumD.z = __builtin_fmaf((YX) * (S), (MZ), B.sumD.z);                                 \
       const float w_ = (ZY) * (WX);                                                          \
       B.sumW += w_; B.sumWV += w_ * (S);                                                     \
     }
@@ -458,11 +467,13 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
 }
 
 // the sample's colour after gradient shading and its opacity after the correction; actual_dt != 0
-template <bool FAST, int STATS>
+template <bool FAST, int STATS, bool HAVE_RCP = false>
 __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, float actual_dt, float cellValue, V3 gradient,
-                                              int finestLevelCellWidth, int channel, const float rcpRange = 0.f)
+                                              float finestLevelCellWidth, int channel, const float rcpRange = 0.f)
 {
-  Color4 sample = lookupXF<FAST>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic, rcpRange);
+  Color4 sample = lookupXF<FAST, HAVE_RCP>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic, rcpRange);
+  // the reference compares with `int finestLevelCellWidth` * 1e-6f (exabrick.cu:1124,1001); the width is an
+  // integer-valued float (a power of two >= 1, checked at scene creation), so the int round trip is the identity
   if (fsqrt<FAST>(dot(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
     const float scale = fdiv<FAST>(fabsf(dot(lightDir, gradient)), fsqrt<FAST>(dot(gradient, gradient) * dot(lightDir, lightDir)));
@@ -487,13 +498,13 @@ __device__ __forceinline__ void compositeSample(Color4 &pixelColor, const Color4
 }
 
 // exabrick.cu:988-1016 integrateVolume
-template <bool FAST, int STATS>
+template <bool FAST, int STATS, bool HAVE_RCP = false>
 __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
-                                                float cellValue, V3 gradient, int finestLevelCellWidth, int channel,
+                                                float cellValue, V3 gradient, float finestLevelCellWidth, int channel,
                                                 const float rcpRange = 0.f)
 {
   if (actual_dt == 0.f) return;
-  const Color4 sample = shadeSample<FAST>(C, ray, actual_dt, cellValue, gradient, finestLevelCellWidth, channel, rcpRange);
+  const Color4 sample = shadeSample<FAST, STATS, HAVE_RCP>(C, ray, actual_dt, cellValue, gradient, finestLevelCellWidth, channel, rcpRange);
   compositeSample(pixelColor, sample);
 }
 
@@ -505,12 +516,15 @@ __device__ __forceinline__ float firstSampleT(float t0, float dt, float off)
 {
   const int i0 = int(ceilf((t0 - dt * off) / dt));
   float t_i = (off + i0) * dt;
+  // the two correction loops almost never run: keep them rolled (unrolled 16x they were 400 instructions)
+#pragma unroll 1
   for (int g = 0; g < 64 && (t_i - dt) >= t0; g++) t_i = t_i - dt;
+#pragma unroll 1
   for (int g = 0; g < 64 && t_i < t0; g++) t_i += dt;
   return t_i;
 }
 // the same with x / dt as x * invDt, for a step that is a power of two (invDt = 1/dt exactly, so quotient and product
-// are the same real number and round alike); the two correction loops almost never run and stay rolled
+// are the same real number and round alike)
 __device__ __forceinline__ float firstSampleTPow2(float t0, float dt, float invDt, float off)
 {
   const int i0 = int(ceilf((t0 - dt * off) * invDt));
@@ -1183,7 +1197,7 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, 
 // one step of the walk: pop / descend one level / accept-or-skip a leaf
 // ISOWALK: the iso march multiplies ray.tmax by dt_scale before every trace (exabrick.cu:1434), so the
 // walk is not clamped at the root; the current tmax clamps t1 at the leaf and ends the walk.
-template <bool ISOWALK, int STATS>
+template <bool ISOWALK, int STATS, bool SMALL = false>
 __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a,
                                        float *stackF, int *qRegion, float *qT, const Ray &ray, const int which,
                                        float &walkTmax, const float dtScale, const KdNodeDev *nodes, const int root)
@@ -1236,7 +1250,9 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
 #endif
   // the popped subtree gets its own look at tmin / tmax in the next call
   if (w.ref < 0 || !(w.tf > walkTmin) || (ISOWALK && !(w.tn < walkTmax))) return;
-  const int4 n = *reinterpret_cast<const int4 *>(nodes + w.ref);
+  // SMALL: the node array is below 4 GiB — uniform base + 32-bit byte offset, no 64-bit address per lane
+  const int4 n = SMALL ? *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)w.ref << 4))
+                       : *reinterpret_cast<const int4 *>(nodes + w.ref);
   C.count(ST_NODES);
   C.phase(ST_W_NODE);
   const float split = __int_as_float(n.x);
@@ -1629,7 +1645,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         for (;;) {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
           if (!__any(want)) break;
-          if (want) kdStep<false>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
+          if (want) kdStep<false, STATS, SMALL>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
         }
       }
       if (!haveSeg) {
@@ -1679,8 +1695,13 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       // brick records are stored along the leaf list (no id indirection); a one-brick region keeps the
       // record it loaded at the start of the segment
       if (listSize > 1 || w.pk.get(PK_NEEDHDR)) {
-        const unsigned at = 2u * (unsigned)(listBegin + child);
-        hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
+        if (SMALL) {                                       // the header array is below 4 GiB
+          const char *hp = reinterpret_cast<const char *>(a.sc.leafHdr) + ((uint32_t)(listBegin + child) << 5);
+          hb0 = *reinterpret_cast<const int4 *>(hp); hb1 = *reinterpret_cast<const int4 *>(hp + 16);
+        } else {
+          const unsigned at = 2u * (unsigned)(listBegin + child);
+          hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
+        }
         w.pk.set(PK_NEEDHDR, 0);
       }
       addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
@@ -1697,8 +1718,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
                             B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
-        integrateVolume<FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, (int)flcw, MULTI ? chan : 0,
-                              (FAST && !MULTI) ? xfRcpRange0 : 0.f);
+        integrateVolume<FAST, STATS, (FAST && !MULTI)>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, MULTI ? chan : 0, xfRcpRange0);
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0;
@@ -2074,7 +2094,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
                             B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
-        smp = shadeSample<FAST>(C, ray, actual_dt, cellValue, grad, (int)flcw, 0);
+        smp = shadeSample<FAST>(C, ray, actual_dt, cellValue, grad, flcw, 0);
         contributes = 1;
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);

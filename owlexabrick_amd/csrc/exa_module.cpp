@@ -806,7 +806,9 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
       h->mul24 = 0;
   }
   if (scene->totalCells >= (1ull << 32)) h->mul24 = 0;
-  h->addr32 = (scene->totalCells + 2) * sizeof(float) <= (1ull << 32) ? 1 : 0;
+  h->addr32 = ((scene->totalCells + 2) * sizeof(float) <= (1ull << 32)              // cell scalars of one field
+               && scene->leafListSize * 32ull < (1ull << 32)                          // march headers
+               && scene->numKdNodes * sizeof(KdNodeDev) < (1ull << 32)) ? 1 : 0;      // kd nodes
   CREATE_TRY(h->scalars.upload(scene->scalars, size_t(scene->numFields) * scene->totalCells));
   std::vector<RegionInfo> ri(scene->numRegions);
   std::vector<float2> vr(scene->numRegions);
@@ -815,6 +817,10 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
     const ExaBrickRegion &R = scene->regions[r];
     if (R.leafListSize < 1 || R.leafListBegin < 0 || uint64_t(R.leafListBegin) + uint64_t(R.leafListSize) > scene->leafListSize) {
       h->fail("exa_hip_create: region leaf list out of range"); return bail();
+    }
+    // finestLevelCellWidth = 2^(min level) (exa/Regions.cpp:293-299): the kernels rely on an integer-valued width >= 1
+    if (!(R.finestLevelCellWidth >= 1.f && R.finestLevelCellWidth <= 1073741824.f) || R.finestLevelCellWidth != std::floor(R.finestLevelCellWidth)) {
+      h->fail("exa_hip_create: region finestLevelCellWidth is not an integer >= 1"); return bail();
     }
     ri[r].listBegin = R.leafListBegin;
     ri[r].listSize = R.leafListSize;
