@@ -4,7 +4,7 @@
 //   exaRender cfg.exa [--size W H] [--camera px py pz  ix iy iz  ux uy uz] [--fov deg]
 //             [--dt f] [--xf file.xf] [--xf-scale s] [--range lo hi] [--isovals a b] [--isochans a b]
 //             [--clip-box lx ly lz ux uy uz] [--ao] [--ao-length l] [--no-pg] [--no-space-skipping]
-//             [--gradientShadingDVR 0|1] [--gradientShadingISO 0|1] [--frames N] [-o out.ppm] [--info]
+//             [--gradientShadingDVR 0|1] [--gradientShadingISO 0|1] [--frames N] [-o out.ppm] [--info] [--stats]
 #include "exa_host.h"
 
 #include <chrono>
@@ -46,7 +46,7 @@ int main(int argc, char **argv)
     vec3f vp, vi, vu;                                             // --camera
     float fov = 70.f, dt = 0.5f, xfScale = 1.f, aoLength = 1e20f;
     float isoVals[2] = { 0, 0 }; int isoChans[2] = { 0, 0 }, isoOn[2] = { 0, 0 };
-    bool haveRange = false, ao = false, pg = true, skipping = true, gradDVR = true, gradISO = true, info = false, clip = false;
+    bool haveRange = false, ao = false, pg = true, skipping = true, gradDVR = true, gradISO = true, info = false, clip = false, stats = false;
     float range[2] = { 0, 1 }; box3f clipBox;
     std::string xfFile;
     int frames = 1;
@@ -72,6 +72,7 @@ int main(int argc, char **argv)
       else if (a == "--frames") frames = (int)f();
       else if (a == "-o") { if (i + 1 >= argc) throw std::runtime_error("missing file after -o"); outName = argv[++i]; }
       else if (a == "--info") info = true;
+      else if (a == "--stats") stats = true;
       else if (a[0] != '-') cfgName = a;
       else throw std::runtime_error("unknown flag " + a);
     }
@@ -119,6 +120,15 @@ int main(int argc, char **argv)
       const box3f wb = renderer.worldSpaceBounds;
       renderer.frameState.clipBox.coords.lower = wb.lower + clipBox.lower * wb.span();
       renderer.frameState.clipBox.coords.upper = wb.lower + clipBox.upper * wb.span();
+    }
+    if (stats) {       // region statistics as Regions::buildFrom prints them, and the work counters of the first frame
+      renderer.updateDt(dt);
+      renderer.updateFrameID(0);
+      const ExaHipStats s = renderer.renderStats();
+      std::printf("regions %zu leafEntries %zu\n", renderer.numRegions, renderer.numLeafEntries);
+      std::printf("stats segments %llu samples %llu brick_visits %llu corner_loads %llu nodes_visited %llu\n",
+                  (unsigned long long)s.segments, (unsigned long long)s.samples, (unsigned long long)s.brick_visits,
+                  (unsigned long long)s.corner_loads, (unsigned long long)s.nodes_visited);
     }
     int accumID = 0;
     double kernelMs = 0;

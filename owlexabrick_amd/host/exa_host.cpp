@@ -323,6 +323,7 @@ Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP> surfaces, std
     throw std::runtime_error(exa_prep_last_error());
   ExaHipScene scene;
   exa_prep_scene(prep, &scene);
+  numRegions = scene.numRegions; numLeafEntries = scene.leafListSize;
   if (exa_hip_create(&scene, device, &handle)) {
     const std::string msg = exa_hip_last_error(nullptr);
     exa_prep_destroy(prep);
@@ -488,6 +489,15 @@ void Renderer::render()
   if (!fbPointer) throw std::runtime_error("resizeFrameBuffer() has not been called");
   pushState();
   check(exa_hip_render(handle, static_cast<uint32_t *>(fbPointer), 0, nullptr, 0), handle);
+}
+
+ExaHipStats Renderer::renderStats()
+{
+  if (!fbPointer) throw std::runtime_error("resizeFrameBuffer() has not been called");
+  pushState();
+  ExaHipStats s;
+  check(exa_hip_render_stats(handle, static_cast<uint32_t *>(fbPointer), 0, &s), handle);
+  return s;
 }
 
 ExaHipStats Renderer::stats() const

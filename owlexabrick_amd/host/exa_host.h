@@ -170,6 +170,8 @@ struct Renderer {
   void render();
 
   ExaHipStats stats() const;
+  ExaHipStats renderStats();                 // the same frame through the counting variant of the kernels
+  size_t numRegions = 0, numLeafEntries = 0; // what Regions::buildFrom produced (exa/Regions.cpp:308-319 prints them)
 
   std::vector<ScalarField::SP> scalarFields;
   ExaBricks::SP input;
