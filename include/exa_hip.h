@@ -160,6 +160,16 @@ const char *exa_prep_last_error(void);
  * on `device`, builds the LBVH over the regions.  The caller's arrays are not
  * referenced after return. */
 int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **out);
+/* One handle that drives several GPUs of one node (SURVEY 8(b) threading row, 8(e)); new relative to the reference,
+ * whose raygen program never reads LaunchParams.deviceIndex/deviceCount (programs/LaunchParams.h:31-32).  The scene is
+ * replicated on every device of the list; device i renders the 16x16 tiles t with t % numDevices == i on a stream of
+ * its own and stores them straight into the destination frame, which lives on devices[0] (the other devices write it
+ * through a peer mapping over xGMI): no gather, no untile.  Every other entry point takes the handle unchanged
+ * (exa_hip_set_shard is refused).  A device destination passed to exa_hip_render must be memory of devices[0]; with
+ * async != 0 the call returns once the work is queued and `hipStream` (a stream of devices[0]) waits for all
+ * devices, so the caller can queue the frame's copy-out behind it and start the next frame into another buffer.
+ * Entries of `devices` may repeat (several renderers on one GPU: rehearsal on a one-GPU box). */
+int exa_hip_create_multi(const ExaHipScene *scene, const int32_t *devices, int32_t numDevices, ExaHipRenderer **out);
 int exa_hip_destroy(ExaHipRenderer *);
 
 /* OptixRenderer::resizeFrameBuffer (exa/OptixRenderer.cpp:341-355): (re)allocates

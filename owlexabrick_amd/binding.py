@@ -86,7 +86,7 @@ KD_EMPTY = -2 ** 31
 
 # every symbol include/exa_hip.h declares
 ABI_SYMBOLS = ["exa_prep_create", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error",
-               "exa_hip_create", "exa_hip_destroy", "exa_hip_resize", "exa_hip_set_frame_state",
+               "exa_hip_create", "exa_hip_create_multi", "exa_hip_destroy", "exa_hip_resize", "exa_hip_set_frame_state",
                "exa_hip_set_xf", "exa_hip_set_triangles", "exa_hip_reset_tracer", "exa_hip_set_tracer_enabled",
                "exa_hip_advance_tracer", "exa_hip_read_traces", "exa_hip_set_params", "exa_hip_set_shard", "exa_hip_output_pixels",
                "exa_hip_untile", "exa_hip_render", "exa_hip_render_stats", "exa_hip_get_stats",
@@ -117,6 +117,7 @@ def lib():
         L.exa_prep_scene.argtypes = [vp, C.POINTER(ExaHipScene)]
         L.exa_prep_last_error.restype = C.c_char_p
         L.exa_hip_create.argtypes = [C.POINTER(ExaHipScene), C.c_int32, C.POINTER(vp)]
+        L.exa_hip_create_multi.argtypes = [C.POINTER(ExaHipScene), C.POINTER(C.c_int32), C.c_int32, C.POINTER(vp)]
         L.exa_hip_destroy.argtypes = [vp]
         L.exa_hip_resize.argtypes = [vp, C.c_int32, C.c_int32]
         L.exa_hip_set_frame_state.argtypes = [vp, C.POINTER(ExaHipFrameState)]
@@ -201,11 +202,16 @@ class Prep:
 class Renderer:
     """Python mirror of exa::OptixRenderer's public methods over the C ABI."""
 
-    def __init__(self, prep, device=0, multiFieldDvr=True):
+    def __init__(self, prep, device=0, multiFieldDvr=True, devices=None):
+        """devices: a list of device indices -> one handle that drives all of them (exa_hip_create_multi)"""
         L = lib()
         self.prep = prep
         self.h = C.c_void_p()
-        rc = L.exa_hip_create(C.byref(prep.scene), device, C.byref(self.h))
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            rc = L.exa_hip_create_multi(C.byref(prep.scene), arr, len(devices), C.byref(self.h))
+        else:
+            rc = L.exa_hip_create(C.byref(prep.scene), device, C.byref(self.h))
         if rc:
             raise RuntimeError(L.exa_hip_last_error(None).decode())
         self.numFields = prep.num_fields

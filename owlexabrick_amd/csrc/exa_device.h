@@ -110,6 +110,8 @@ struct RenderArgs {
   int32_t            rank, world;   // image-space shard
   const int32_t     *tileMap;       // blockIdx.x -> global tile id (launch order)
   uint32_t          *color;
+  int32_t            colorRowMajor; // sharded handle whose colour goes row-major into a full frame (multi-device handle:
+                                    // a peer-mapped pointer to the root device's buffer); accum / surf stay tile-major
   float4            *accum;
   float4            *surf;          // surfaces pre-pass -> march: {background rgb, surface t_hit} per pixel slot
   uint32_t          *surfRnd;       // LCG state after the pre-pass' draws

@@ -1100,7 +1100,8 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
     a.accum[slot] = make_float4(cr, cg, cb, 1.f);                                 // :1712
     const float div = frameID + 1.f;
     cr = cr / div; cg = cg / div; cb = cb / div;
-    a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+    // colorRowMajor: a device of a multi-device handle stores its tiles straight into the root's row-major frame
+    a.color[a.colorRowMajor ? size_t(px) + size_t(a.W) * py : slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
   }
 
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
@@ -1758,7 +1759,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     // The pixel's framebuffer slot is worked out again from the thread id instead of being kept in two registers
     // across the march (the kernel runs at exactly 80 VGPRs; the asm keeps the compiler from re-using the value
     // computed before the loop).
-    size_t slot;
+    size_t slot, colorSlot;               // colorSlot: row-major in the root's frame for a device of a multi-device handle
     {
       unsigned tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
@@ -1766,6 +1767,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       const int inX2 = ((wave2 & 1) << 3) + (lane2 & 7), inY2 = ((wave2 >> 1) << 3) + (lane2 >> 3);
       slot = (a.world == 1) ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2)
                             : size_t(tile / a.world) * kTilePixels + (inY2 * kTile + inX2);
+      colorSlot = a.colorRowMajor ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2) : slot;
     }
     float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
     if (SURF) bgColor = a.surf[slot];
@@ -1780,7 +1782,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     a.accum[slot] = make_float4(cr, cg, cb, 1.f);
     const float div = frameID + 1.f;
     cr = cr / div; cg = cg / div; cb = cb / div;
-    a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+    a.color[colorSlot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
   }
 
   if (a.tileCost) {
@@ -2146,7 +2148,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       a.accum[slot] = make_float4(cr, cg, cb, 1.f);
       const float div = frameID + 1.f;
       cr = cr / div; cg = cg / div; cb = cb / div;
-      a.color[slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+      a.color[a.colorRowMajor ? size_t(px) + size_t(a.W) * py : slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
     }
   }
   if (a.tileCost) {

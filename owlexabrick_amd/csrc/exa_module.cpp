@@ -187,6 +187,14 @@ struct ExaHipRenderer {
   std::string err;
   void fail(const std::string &m) { err = m; }
 
+  // multi-device handle (exa_hip_create_multi): this object only fans out to `children`, one complete renderer per
+  // entry of the device list, each owning the tiles t with t % n == i and storing them straight into the root
+  // device's row-major frame (peer-mapped pointer)
+  std::vector<ExaHipRenderer *> children;
+  bool colorRowMajor = false;          // a child: colour goes row-major into the destination frame
+  hipStream_t ownStream = nullptr;     // a child's launch stream
+  hipEvent_t evCall = nullptr;         // multi handle: the caller's stream position at the start of a frame
+
   // scene
   DevBuf<int4> bricks;
   DevBuf<int32_t> leafList;
@@ -651,6 +659,7 @@ struct ExaHipRenderer {
     a.rank = rank; a.world = world;
     a.tileMap = tileMap.p;
     a.color = dstDevice;
+    a.colorRowMajor = colorRowMajor ? 1 : 0;
     a.accum = accum.p;
     a.surf = surf.p;
     a.surfRnd = surfRnd.p;
@@ -976,10 +985,51 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   return 0;
 }
 
+// One handle, several devices: the scene is replicated, device i renders the 16x16 tiles t with t % n == i and stores
+// them straight into the destination frame on the first device of the list (peer-mapped when it is another device), so
+// there is no gather and no untile step.  Entries of `devices` may repeat (several renderers sharing one GPU: rehearsal).
+int exa_hip_create_multi(const ExaHipScene *scene, const int32_t *devices, int32_t numDevices, ExaHipRenderer **out)
+{
+  if (!out || !scene || !devices || numDevices < 1 || numDevices > 64) { g_createError = "exa_hip_create_multi: bad arguments"; return 1; }
+  *out = nullptr;
+  ExaHipRenderer *h = new ExaHipRenderer;
+  h->device = devices[0];
+  auto bail = [&](const std::string &msg) { g_createError = msg; exa_hip_destroy(h); return 1; };
+  for (int i = 0; i < numDevices; i++) {
+    ExaHipRenderer *c = nullptr;
+    if (int rc = exa_hip_create(scene, devices[i], &c)) { exa_hip_destroy(h); return rc; }    // g_createError is set
+    h->children.push_back(c);
+    c->colorRowMajor = true;
+    c->rank = i; c->world = numDevices; c->layoutDirty = true;
+    DeviceGuard g(devices[i]);
+    if (g.err != hipSuccess || hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess)
+      return bail("exa_hip_create_multi: cannot create a stream on device " + std::to_string(devices[i]));
+    if (devices[i] != devices[0]) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) != hipSuccess || !can)
+        return bail("exa_hip_create_multi: device " + std::to_string(devices[i]) + " cannot access device " + std::to_string(devices[0]));
+      const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return bail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
+  }
+  {
+    DeviceGuard g(devices[0]);
+    if (g.err != hipSuccess || hipEventCreateWithFlags(&h->evCall, hipEventDisableTiming) != hipSuccess) return bail("exa_hip_create_multi: hipEventCreate failed");
+  }
+  h->numFields = h->children[0]->numFields;
+  *out = h;
+  return 0;
+}
+
 int exa_hip_destroy(ExaHipRenderer *h)
 {
   if (!h) return 0;
+  for (ExaHipRenderer *c : h->children) exa_hip_destroy(c);
+  h->children.clear();
   DeviceGuard guard_(h->device);
+  if (h->ownStream) (void)hipStreamDestroy(h->ownStream);
+  if (h->evCall) (void)hipEventDestroy(h->evCall);
   (void)hipDeviceSynchronize();
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -997,6 +1047,15 @@ int exa_hip_destroy(ExaHipRenderer *h)
 
 int exa_hip_resize(ExaHipRenderer *h, int32_t width, int32_t height)
 {
+  if (h && !h->children.empty()) {
+    if (width <= 0 || height <= 0 || int64_t(width) * height > (int64_t(1) << 30)) { h->fail("exa_hip_resize: bad size"); return 1; }
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_resize(c, width, height)) { h->fail(c->err); return rc; }
+    h->W = width; h->H = height;
+    EXA_ON_DEVICE(h);                         // the root device holds the frame a host destination is copied from
+    HIP_TRY(h, h->color.alloc(size_t(width) * height));
+    return 0;
+  }
   if (!h) return 1;
   if (width <= 0 || height <= 0 || int64_t(width) * height > (int64_t(1) << 30)) { h->fail("exa_hip_resize: bad size"); return 1; }
   EXA_ON_DEVICE(h);
@@ -1007,6 +1066,11 @@ int exa_hip_resize(ExaHipRenderer *h, int32_t width, int32_t height)
 
 int exa_hip_set_frame_state(ExaHipRenderer *h, const ExaHipFrameState *fs)
 {
+  if (h && !h->children.empty()) {            // multi-device handle: the same call on every device's renderer
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_set_frame_state(c, fs)) { h->fail(c->err); return rc; }
+    return 0;
+  }
   if (!h || !fs) return 1;
   if (!h->haveFs || std::memcmp(h->fs.xfDomain, fs->xfDomain, sizeof(fs->xfDomain)) != 0
       || h->fs.xfOpacityScale != fs->xfOpacityScale) h->volDirty = true;
@@ -1024,6 +1088,11 @@ int exa_hip_set_frame_state(ExaHipRenderer *h, const ExaHipFrameState *fs)
 
 int exa_hip_set_xf(ExaHipRenderer *h, int32_t chan, const float *rgba128)
 {
+  if (h && !h->children.empty()) {            // multi-device handle: the same call on every device's renderer
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_set_xf(c, chan, rgba128)) { h->fail(c->err); return rc; }
+    return 0;
+  }
   if (!h || !rgba128) return 1;
   if (chan < 0 || chan >= EXA_MAX_CHANNELS) { h->fail("exa_hip_set_xf: bad channel"); return 1; }
   std::memcpy(h->xfHost[chan], rgba128, sizeof(h->xfHost[chan]));
@@ -1036,6 +1105,11 @@ int exa_hip_set_xf(ExaHipRenderer *h, int32_t chan, const float *rgba128)
 int exa_hip_set_triangles(ExaHipRenderer *h, const float *vertices, uint64_t numVertices,
                           const int32_t *triangles, uint64_t numTris)
 {
+  if (h && !h->children.empty()) {            // multi-device handle: the same call on every device's renderer
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_set_triangles(c, vertices, numVertices, triangles, numTris)) { h->fail(c->err); return rc; }
+    return 0;
+  }
   if (!h) return 1;
   EXA_ON_DEVICE(h);
   HIP_TRY(h, hipDeviceSynchronize());
@@ -1084,6 +1158,11 @@ int exa_hip_set_triangles(ExaHipRenderer *h, const float *vertices, uint64_t num
 
 int exa_hip_reset_tracer(ExaHipRenderer *h, const ExaHipTracer *t, const float *seeds)
 {
+  if (h && !h->children.empty()) {            // multi-device handle: the same call on every device's renderer
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_reset_tracer(c, t, seeds)) { h->fail(c->err); return rc; }
+    return 0;
+  }
   if (!h || !t || !seeds) return 1;
   if (t->numTraces < 0 || t->numTimesteps < 2 || (long long)t->numTraces * t->numTimesteps > (1ll << 28)) { h->fail("exa_hip_reset_tracer: bad trace counts"); return 1; }
   for (int k = 0; k < 3; k++)
@@ -1102,6 +1181,11 @@ int exa_hip_reset_tracer(ExaHipRenderer *h, const ExaHipTracer *t, const float *
 
 int exa_hip_set_tracer_enabled(ExaHipRenderer *h, int32_t enabled)
 {
+  if (h && !h->children.empty()) {            // multi-device handle: the same call on every device's renderer
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_set_tracer_enabled(c, enabled)) { h->fail(c->err); return rc; }
+    return 0;
+  }
   if (!h) return 1;
   h->tracer.enabled = enabled;
   return 0;
@@ -1109,6 +1193,14 @@ int exa_hip_set_tracer_enabled(ExaHipRenderer *h, int32_t enabled)
 
 int exa_hip_advance_tracer(ExaHipRenderer *h, int32_t *rebuild)
 {
+  if (h && !h->children.empty()) {
+    for (size_t i = 0; i < h->children.size(); i++) {
+      int32_t r = 0;
+      if (int rc = exa_hip_advance_tracer(h->children[i], &r)) { h->fail(h->children[i]->err); return rc; }
+      if (i == 0 && rebuild) *rebuild = r;
+    }
+    return 0;
+  }
   if (!h) return 1;
   if (rebuild) *rebuild = 0;
   if (!h->haveTracer || !h->tracer.enabled) return 0;
@@ -1120,6 +1212,11 @@ int exa_hip_advance_tracer(ExaHipRenderer *h, int32_t *rebuild)
 
 int exa_hip_read_traces(ExaHipRenderer *h, float *dst)
 {
+  if (h && !h->children.empty()) {             // every device holds the same traces
+    const int rc = exa_hip_read_traces(h->children[0], dst);
+    if (rc) h->fail(h->children[0]->err);
+    return rc;
+  }
   if (!h || !dst || !h->haveTracer) return 1;
   EXA_ON_DEVICE(h);
   HIP_TRY(h, hipDeviceSynchronize());
@@ -1129,6 +1226,11 @@ int exa_hip_read_traces(ExaHipRenderer *h, float *dst)
 
 int exa_hip_set_params(ExaHipRenderer *h, const ExaHipParams *p)
 {
+  if (h && !h->children.empty()) {            // multi-device handle: the same call on every device's renderer
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_set_params(c, p)) { h->fail(c->err); return rc; }
+    return 0;
+  }
   if (!h || !p) return 1;
   if (!(p->dt > 0.f)) { h->fail("exa_hip_set_params: dt must be > 0"); return 1; }
   if (!h->haveParams || h->p.numChannels != p->numChannels || h->p.spaceSkippingEnabled != p->spaceSkippingEnabled)
@@ -1141,6 +1243,7 @@ int exa_hip_set_params(ExaHipRenderer *h, const ExaHipParams *p)
 
 int exa_hip_set_shard(ExaHipRenderer *h, int32_t rank, int32_t worldSize)
 {
+  if (h && !h->children.empty()) { h->fail("exa_hip_set_shard: a multi-device handle shards the frame internally"); return 1; }
   if (!h) return 1;
   if (worldSize < 1 || rank < 0 || rank >= worldSize) { h->fail("exa_hip_set_shard: bad rank/world"); return 1; }
   h->rank = rank; h->world = worldSize;
@@ -1151,6 +1254,11 @@ int exa_hip_set_shard(ExaHipRenderer *h, int32_t rank, int32_t worldSize)
 
 int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
 {
+  if (h && !h->children.empty()) {            // multi-device handle: the same call on every device's renderer
+    for (ExaHipRenderer *c : h->children)
+      if (int rc = exa_hip_set_option(c, key, value)) { h->fail(c->err); return rc; }
+    return 0;
+  }
   if (!h || !key) return 1;
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "tile_feedback")) { h->feedback = value; h->layoutDirty = true; return 0; }
@@ -1177,12 +1285,81 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
 uint64_t exa_hip_output_pixels(const ExaHipRenderer *h)
 {
   if (!h || h->W <= 0) return 0;
+  if (!h->children.empty()) return uint64_t(h->W) * h->H;
   return h->world <= 1 ? uint64_t(h->W) * h->H : h->outputPixels();
+}
+
+// A frame of a multi-device handle: every device marches its tiles into the same destination frame on its own stream;
+// the caller's stream waits for all of them (async) or the host does (synchronous).
+static int renderMulti(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, hipStream_t s, bool async, bool stats)
+{
+  if (h->W <= 0) { h->fail("exa_hip_render: framebuffer not sized"); return 1; }
+  uint32_t *dst = dstIsDevice && rgba8 ? rgba8 : h->color.p;
+  const bool willSync = !(async && dstIsDevice && !stats);
+  {
+    EXA_ON_DEVICE(h);
+    HIP_TRY(h, hipEventRecord(h->evCall, s));           // what the caller queued before (e.g. the copy-out of this buffer)
+  }
+  for (ExaHipRenderer *c : h->children) {
+    DeviceGuard g(c->device);
+    if (g.err != hipSuccess) { h->fail("hipSetDevice failed"); return 1; }
+    HIP_TRY(h, hipStreamWaitEvent(c->ownStream, h->evCall, 0));
+    if (c->prepareFrame(c->ownStream)) { h->fail(c->err); return 1; }
+    if (stats) HIP_TRY(h, hipMemsetAsync(c->statsBuf.p, 0, ST_COUNT * sizeof(unsigned long long), c->ownStream));
+    c->measureCosts = willSync && !stats;
+    if (c->launch(dst, stats, c->ownStream)) { h->fail(c->err); return 1; }
+  }
+  if (!willSync) {
+    EXA_ON_DEVICE(h);
+    for (ExaHipRenderer *c : h->children) HIP_TRY(h, hipStreamWaitEvent(s, c->ev1, 0));
+    return 0;
+  }
+  ExaHipStats sum{};
+  for (ExaHipRenderer *c : h->children) {
+    DeviceGuard g(c->device);
+    HIP_TRY(h, hipEventSynchronize(c->ev1));
+    HIP_TRY(h, hipEventElapsedTime(&c->last.kernel_ms, c->ev0, c->ev1));
+    if (c->measureCosts && c->feedback && c->costPhase == 1 && c->useKd() && c->reorderFromCosts()) { h->fail(c->err); return 1; }
+    int32_t flag = 0;
+    HIP_TRY(h, hipMemcpy(&flag, c->errorFlag.p, sizeof(flag), hipMemcpyDeviceToHost));
+    if (flag) {
+      (void)hipMemset(c->errorFlag.p, 0, sizeof(int32_t));
+      h->fail("exa_hip_render: a ray-march loop guard tripped (step size too small for the ray length?)");
+      return 3;
+    }
+    sum.kernel_ms = std::max(sum.kernel_ms, c->last.kernel_ms);
+    sum.rebuild_ms = std::max(sum.rebuild_ms, c->last.rebuild_ms);
+    sum.node_bytes = c->last.node_bytes;
+    if (stats) {
+      unsigned long long k[ST_COUNT];
+      HIP_TRY(h, hipMemcpy(k, c->statsBuf.p, sizeof(k), hipMemcpyDeviceToHost));
+      sum.segments += k[ST_SEGMENTS]; sum.sample_evals += k[ST_SAMPLE_EVALS]; sum.samples += k[ST_SAMPLES];
+      sum.brick_visits += k[ST_BRICK_VISITS]; sum.corner_loads += k[ST_CORNER_LOADS];
+      sum.iso_segments += k[ST_ISO_SEGMENTS]; sum.iso_evals += k[ST_ISO_EVALS]; sum.nodes_visited += k[ST_NODES];
+      for (int i = 0; i < 9; i++) sum.diag[i] += k[ST_W_BRICK + i];
+      for (int i = 0; i < 5; i++) sum.phase_cycles[i] += k[ST_T_BRICK + i];
+    }
+  }
+  sum.pixels = uint64_t(h->W) * h->H;
+  if (!stats) {                                  // keep the counters of the last counted frame, as a single-device handle does
+    const ExaHipStats keep = h->last;
+    sum.segments = keep.segments; sum.sample_evals = keep.sample_evals; sum.samples = keep.samples; sum.brick_visits = keep.brick_visits;
+    sum.corner_loads = keep.corner_loads; sum.iso_segments = keep.iso_segments; sum.iso_evals = keep.iso_evals; sum.nodes_visited = keep.nodes_visited;
+    for (int i = 0; i < 9; i++) sum.diag[i] = keep.diag[i];
+    for (int i = 0; i < 5; i++) sum.phase_cycles[i] = keep.phase_cycles[i];
+  }
+  h->last = sum;
+  if (!dstIsDevice && rgba8) {
+    EXA_ON_DEVICE(h);
+    HIP_TRY(h, hipMemcpy(rgba8, h->color.p, size_t(h->W) * h->H * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  }
+  return 0;
 }
 
 static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, hipStream_t s, bool async, bool stats)
 {
   if (!h) return 1;
+  if (!h->children.empty()) return renderMulti(h, rgba8, dstIsDevice, s, async, stats);
   EXA_ON_DEVICE(h);
   if (h->prepareFrame(s)) return 1;
   uint32_t *dst = dstIsDevice && rgba8 ? rgba8 : h->color.p;
@@ -1229,6 +1406,13 @@ int exa_hip_render_stats(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice
 int exa_hip_get_stats(ExaHipRenderer *h, ExaHipStats *out)
 {
   if (!h || !out) return 1;
+  if (!h->children.empty()) {                  // kernel time of the slowest device (refreshed if an async frame has completed)
+    float ms = 0.f;
+    for (ExaHipRenderer *c : h->children) { ExaHipStats s; exa_hip_get_stats(c, &s); ms = std::max(ms, s.kernel_ms); }
+    h->last.kernel_ms = ms;
+    *out = h->last;
+    return 0;
+  }
   // refresh the kernel time of an async launch if it has completed
   if (h->ev0 && hipEventQuery(h->ev1) == hipSuccess) (void)hipEventElapsedTime(&h->last.kernel_ms, h->ev0, h->ev1);
   *out = h->last;
@@ -1244,9 +1428,35 @@ int exa_hip_untile(ExaHipRenderer *h, const uint32_t *gathered, uint64_t shardSt
   return 0;
 }
 
+// row-major frame <-> the tile-major shards of a multi-device handle's children (host side)
+static int multiAccum(ExaHipRenderer *h, float *frame4, bool read)
+{
+  const int n = (int)h->children.size(), W = h->W, H = h->H;
+  const int tilesX = (W + kTile - 1) / kTile, tilesY = (H + kTile - 1) / kTile;
+  for (int i = 0; i < n; i++) {
+    ExaHipRenderer *c = h->children[i];
+    if (c->accum.n == 0) continue;                 // more devices than tiles: this one owns nothing
+    std::vector<float> shard(c->accum.n * 4);
+    if (read && exa_hip_read_accum(c, shard.data())) { h->fail(c->err); return 1; }
+    if (!read && exa_hip_read_accum(c, shard.data())) { h->fail(c->err); return 1; }   // keep the padding pixels of ragged tiles
+    for (int t = i; t < tilesX * tilesY; t += n) {
+      const int tx = t % tilesX, ty = t / tilesX;
+      for (int y = 0; y < kTile && ty * kTile + y < H; y++)
+        for (int x = 0; x < kTile && tx * kTile + x < W; x++) {
+          float *f = frame4 + 4 * (size_t(tx * kTile + x) + size_t(W) * (ty * kTile + y));
+          float *s = shard.data() + 4 * (size_t(t / n) * kTilePixels + size_t(y) * kTile + x);
+          for (int k = 0; k < 4; k++) { if (read) f[k] = s[k]; else s[k] = f[k]; }
+        }
+    }
+    if (!read && exa_hip_write_accum(c, shard.data())) { h->fail(c->err); return 1; }
+  }
+  return 0;
+}
+
 int exa_hip_read_accum(ExaHipRenderer *h, float *dst4)
 {
   if (!h || !dst4) return 1;
+  if (!h->children.empty()) return multiAccum(h, dst4, true);
   EXA_ON_DEVICE(h);
   HIP_TRY(h, hipMemcpy(dst4, h->accum.p, h->accum.n * sizeof(float4), hipMemcpyDeviceToHost));
   return 0;
@@ -1255,6 +1465,7 @@ int exa_hip_read_accum(ExaHipRenderer *h, float *dst4)
 int exa_hip_write_accum(ExaHipRenderer *h, const float *src4)
 {
   if (!h || !src4) return 1;
+  if (!h->children.empty()) return multiAccum(h, const_cast<float *>(src4), false);
   EXA_ON_DEVICE(h);
   HIP_TRY(h, hipMemcpy(h->accum.p, src4, h->accum.n * sizeof(float4), hipMemcpyHostToDevice));
   return 0;
@@ -1262,6 +1473,11 @@ int exa_hip_write_accum(ExaHipRenderer *h, const float *src4)
 
 int exa_hip_read_activity(ExaHipRenderer *h, int32_t which, uint8_t *dst)
 {
+  if (h && !h->children.empty()) {
+    const int rc = exa_hip_read_activity(h->children[0], which, dst);
+    if (rc) h->fail(h->children[0]->err);
+    return rc;
+  }
   if (!h || !dst) return 1;
   EXA_ON_DEVICE(h);
   if (h->prepareFrame(nullptr)) return 1;

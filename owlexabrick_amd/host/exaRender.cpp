@@ -5,7 +5,13 @@
 //             [--dt f] [--xf file.xf] [--xf-scale s] [--range lo hi] [--isovals a b] [--isochans a b]
 //             [--clip-box lx ly lz ux uy uz] [--ao] [--ao-length l] [--no-pg] [--no-space-skipping]
 //             [--gradientShadingDVR 0|1] [--gradientShadingISO 0|1] [--frames N] [-o out.ppm] [--info] [--stats]
+//             [--gpus N | --devices 0,1,..]  one renderer over several GPUs (tiles dealt round-robin, stored straight into
+//                                            the first device's frame); a device may be listed more than once
+//             [--pipeline]                   frames go to two device buffers in turn, frame k's copy to the host overlaps
+//                                            frame k+1's march
 #include "exa_host.h"
+
+#include <hip/hip_runtime.h>
 
 #include <chrono>
 #include <cstdio>
@@ -50,6 +56,8 @@ int main(int argc, char **argv)
     float range[2] = { 0, 1 }; box3f clipBox;
     std::string xfFile;
     int frames = 1;
+    std::vector<int> devices;
+    bool pipeline = false;
     for (int i = 1; i < argc; i++) {
       const std::string a = argv[i];
       auto f = [&]() { if (i + 1 >= argc) throw std::runtime_error("missing value after " + a); return (float)atof(argv[++i]); };
@@ -73,6 +81,13 @@ int main(int argc, char **argv)
       else if (a == "-o") { if (i + 1 >= argc) throw std::runtime_error("missing file after -o"); outName = argv[++i]; }
       else if (a == "--info") info = true;
       else if (a == "--stats") stats = true;
+      else if (a == "--gpus") { const int n = (int)f(); devices.clear(); for (int d = 0; d < n; d++) devices.push_back(d); }
+      else if (a == "--devices") {
+        if (i + 1 >= argc) throw std::runtime_error("missing list after --devices");
+        devices.clear();
+        for (const char *p = argv[++i]; *p;) { devices.push_back((int)strtol(p, const_cast<char **>(&p), 10)); if (*p == ',') p++; }
+      }
+      else if (a == "--pipeline") pipeline = true;
       else if (a[0] != '-') cfgName = a;
       else throw std::runtime_error("unknown flag " + a);
     }
@@ -89,7 +104,9 @@ int main(int argc, char **argv)
     if (info) return 0;
 
     std::vector<uint32_t> fb(size_t(size.x) * size.y);
-    Renderer renderer(config->bricks.sp, config->surfaces, config->scalarFields);          // viewer.cpp:1256-1260
+    if (devices.empty()) devices.push_back(0);
+    Renderer renderer(config->bricks.sp, config->surfaces, config->scalarFields, devices);  // viewer.cpp:1256-1260
+    if (devices.size() > 1) std::printf("devices %zu\n", devices.size());
     renderer.setVoxelSpaceTransform(config->bricks.voxelSpaceTransform);
     renderer.resizeFrameBuffer(fb.data(), size);
     if (vu != vec3f(0.f)) setupCamera(renderer, vp, vi, vu, fov, size);
@@ -133,12 +150,53 @@ int main(int argc, char **argv)
     int accumID = 0;
     double kernelMs = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    for (int fr = 0; fr < frames; fr++) {                            // viewer.cpp:279-288
+    if (!pipeline) {
+      for (int fr = 0; fr < frames; fr++) {                          // viewer.cpp:279-288
+        renderer.updateDt(dt);
+        renderer.updateFrameID(accumID);
+        if (pg) ++accumID;
+        renderer.render();
+        kernelMs += renderer.stats().kernel_ms;
+      }
+    } else {
+      // two device frames + two pinned host frames: the march of frame k+1 runs while frame k travels to the host
+      auto ok = [](hipError_t e, const char *what) { if (e != hipSuccess) throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e)); };
+      ok(hipSetDevice(devices[0]), "hipSetDevice");
+      const size_t bytes = fb.size() * sizeof(uint32_t);
+      uint32_t *dev[2], *host[2];
+      hipStream_t march, copy;
+      hipEvent_t rendered[2], copied[2];
+      ok(hipStreamCreateWithFlags(&march, hipStreamNonBlocking), "hipStreamCreate");
+      ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking), "hipStreamCreate");
+      for (int k = 0; k < 2; k++) {
+        ok(hipMalloc((void **)&dev[k], bytes), "hipMalloc");
+        ok(hipHostMalloc((void **)&host[k], bytes, hipHostMallocDefault), "hipHostMalloc");
+        ok(hipEventCreateWithFlags(&rendered[k], hipEventDisableTiming), "hipEventCreate");
+        ok(hipEventCreateWithFlags(&copied[k], hipEventDisableTiming), "hipEventCreate");
+      }
       renderer.updateDt(dt);
-      renderer.updateFrameID(accumID);
-      if (pg) ++accumID;
-      renderer.render();
-      kernelMs += renderer.stats().kernel_ms;
+      renderer.updateFrameID(0);
+      renderer.render();                                   // one synchronous frame first: launch-order feedback
+      const auto t1 = std::chrono::steady_clock::now();
+      for (int fr = 0; fr < frames; fr++) {
+        const int k = fr & 1;
+        renderer.updateFrameID(accumID);
+        if (pg) ++accumID;
+        if (fr >= 2) ok(hipStreamWaitEvent(march, copied[k], 0), "hipStreamWaitEvent");   // buffer k has left the device
+        renderer.renderAsync(dev[k], march);
+        ok(hipEventRecord(rendered[k], march), "hipEventRecord");
+        ok(hipStreamWaitEvent(copy, rendered[k], 0), "hipStreamWaitEvent");
+        ok(hipMemcpyAsync(host[k], dev[k], bytes, hipMemcpyDeviceToHost, copy), "hipMemcpyAsync");
+        ok(hipEventRecord(copied[k], copy), "hipEventRecord");
+      }
+      ok(hipStreamSynchronize(copy), "hipStreamSynchronize");
+      ok(hipStreamSynchronize(march), "hipStreamSynchronize");
+      const double secP = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+      std::memcpy(fb.data(), host[(frames - 1) & 1], bytes);
+      kernelMs = renderer.stats().kernel_ms * frames;
+      std::printf("pipelined: %d frames in %.3f ms (%.3f ms per frame incl. copy to host)\n", frames, 1000.0 * secP, 1000.0 * secP / frames);
+      for (int k = 0; k < 2; k++) { (void)hipFree(dev[k]); (void)hipHostFree(host[k]); (void)hipEventDestroy(rendered[k]); (void)hipEventDestroy(copied[k]); }
+      (void)hipStreamDestroy(march); (void)hipStreamDestroy(copy);
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     std::printf("Avg. after %d frames: %.3f FPS (%.3f ms), kernel %.3f ms\n", frames, frames / sec, 1000.0 * sec / frames, kernelMs / frames);

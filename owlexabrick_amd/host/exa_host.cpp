@@ -310,7 +310,18 @@ static void check(int rc, ExaHipRenderer *h)
 
 Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP> surfaces, std::vector<ScalarField::SP> fields, int device)
   : scalarFields(fields), input(in)
+{ init(surfaces, std::vector<int>(1, device)); }
+
+Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP> surfaces, std::vector<ScalarField::SP> fields,
+                   const std::vector<int> &devices)
+  : scalarFields(fields), input(in)
+{ init(surfaces, devices); }
+
+void Renderer::init(std::vector<TriangleMesh::SP> surfaces, const std::vector<int> &devices)
 {
+  ExaBricks::SP in = input;
+  std::vector<ScalarField::SP> &fields = scalarFields;
+  if (devices.empty()) throw std::runtime_error("no device");
   if (!in || in->numBricks() == 0) throw std::runtime_error("no bricks");
   if (fields.empty() || (int)fields.size() > MAX_CHANNELS) throw std::runtime_error("1..10 scalar fields required");
   voxelSpaceBounds = in->getBounds();
@@ -324,7 +335,9 @@ Renderer::Renderer(ExaBricks::SP in, std::vector<TriangleMesh::SP> surfaces, std
   ExaHipScene scene;
   exa_prep_scene(prep, &scene);
   numRegions = scene.numRegions; numLeafEntries = scene.leafListSize;
-  if (exa_hip_create(&scene, device, &handle)) {
+  std::vector<int32_t> devs(devices.begin(), devices.end());
+  if (devs.size() == 1 ? exa_hip_create(&scene, devs[0], &handle)
+                       : exa_hip_create_multi(&scene, devs.data(), (int32_t)devs.size(), &handle)) {
     const std::string msg = exa_hip_last_error(nullptr);
     exa_prep_destroy(prep);
     prep = nullptr;
@@ -489,6 +502,12 @@ void Renderer::render()
   if (!fbPointer) throw std::runtime_error("resizeFrameBuffer() has not been called");
   pushState();
   check(exa_hip_render(handle, static_cast<uint32_t *>(fbPointer), 0, nullptr, 0), handle);
+}
+
+void Renderer::renderAsync(void *deviceColorBuffer, void *hipStream)
+{
+  pushState();
+  check(exa_hip_render(handle, static_cast<uint32_t *>(deviceColorBuffer), 1, hipStream, 1), handle);
 }
 
 ExaHipStats Renderer::renderStats()

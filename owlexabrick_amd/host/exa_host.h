@@ -149,6 +149,10 @@ struct Renderer {
   typedef std::shared_ptr<Renderer> SP;
   Renderer(ExaBricks::SP input, std::vector<TriangleMesh::SP> surfaces, std::vector<ScalarField::SP> scalarFields,
            int device = 0);
+  // one renderer that drives several GPUs of the node (exa_hip_create_multi): image tiles dealt round-robin, every
+  // device stores its tiles straight into the frame on devices[0]
+  Renderer(ExaBricks::SP input, std::vector<TriangleMesh::SP> surfaces, std::vector<ScalarField::SP> scalarFields,
+           const std::vector<int> &devices);
   ~Renderer();
   Renderer(const Renderer &) = delete;
 
@@ -168,6 +172,9 @@ struct Renderer {
   void resetTracer();
   bool advanceTracer();
   void render();
+  // the frame into a DEVICE buffer (memory of the first device), queued on `hipStream` without waiting: the caller
+  // orders its copy-out behind it on that stream and may start the next frame into another buffer meanwhile
+  void renderAsync(void *deviceColorBuffer, void *hipStream);
 
   ExaHipStats stats() const;
   ExaHipStats renderStats();                 // the same frame through the counting variant of the kernels
@@ -192,6 +199,7 @@ struct Renderer {
   } traces;
 
 private:
+  void init(std::vector<TriangleMesh::SP> surfaces, const std::vector<int> &devices);
   void pushState();
   ExaPrep *prep = nullptr;
   ExaHipRenderer *handle = nullptr;
