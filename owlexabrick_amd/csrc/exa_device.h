@@ -4,6 +4,8 @@
 #include "../../include/exa_hip.h"
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 namespace exa {
 
 // One LBVH node = 64 bytes = four 16-byte loads.  Both children's boxes live in
@@ -122,6 +124,10 @@ struct RenderArgs {
   float4            *wideSegs;      // wide march: [tile of this launch][ray][window][kWideSegCap] {record, tn, tf, -}
   uint32_t          *tileCost;      // != null: per tile id, brick visits of the tile's longest ray (launch-order feedback)
 };
+
+// ---- exa_lbvh.hip: LBVH topology over numPrims boxes (6 floats each, device), built on the device ----
+hipError_t buildLbvhTopologyDevice(const float *boxes, uint32_t numPrims, BvhNode *nodes, int32_t *levelIds,
+                                   std::vector<uint32_t> &internalNodesPerDepth, hipStream_t s);
 
 // ---- launchers implemented in exa_kernels.hip ----
 hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s);

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -236,8 +237,6 @@ struct ExaHipRenderer {
   // LBVH
   DevBuf<BvhNode> volNodes, isoNodes;
   DevBuf<int32_t> levelIds;
-  std::vector<int> levelBegin;      // per height class, offsets into levelIds
-  std::vector<BvhNode> topoTemplate; // children filled, boxes empty (for the lazily created iso LBVH)
   DevBuf<uint8_t> volActive, isoActive;
   bool volDirty = true, isoDirty = true;
 
@@ -496,53 +495,79 @@ struct ExaHipRenderer {
   bool useKd() const { return haveKd && accel == 1; }
 
   // The LBVH over the regions (north_star's structure; accel=0, scenes without a kd-tree, and the
-  // streamline tracer's point queries) is built on first use: Morton-sorted regions, topology on the
-  // host from the region domains read back from the device, boxes filled by the refit.
+  // streamline tracer's point queries) is built on first use, on the device (exa_lbvh.hip): Morton codes, radix
+  // sort, topology level by level; boxes are filled by the refit.  Option lbvh_build = 1 builds the same tree on
+  // the host instead (LbvhTopology above; the two are identical node for node, tests compare them).
   bool lbvhBuilt = false;
+  int lbvhOnHost = 0;
+  std::vector<std::pair<int, int>> levelRanges;   // (offset into levelIds, count) per refit launch, children before parents
+  DevBuf<BvhNode> topoNodes;                       // children filled, boxes empty: the template of volNodes / isoNodes
   int ensureLbvh()
   {
     if (lbvhBuilt) return 0;
     const size_t nr = domain.n / 6;
-    std::vector<float> boxes(domain.n);
-    HIP_TRY(this, hipMemcpy(boxes.data(), domain.p, domain.n * sizeof(float), hipMemcpyDeviceToHost));
-    LbvhTopology topo;
-    topo.build(boxes.data(), nr);
-    boxes.clear(); boxes.shrink_to_fit();
-    const size_t ni = topo.child0.size();
-    topoTemplate.resize(ni);
-    for (size_t i = 0; i < ni; i++) {
-      BvhNode &n = topoTemplate[i];
-      n.q0 = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX);
-      n.q1 = make_float4(-FLT_MAX, -FLT_MAX, FLT_MAX, FLT_MAX);
-      n.q2 = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
-      n.child0 = topo.child0[i]; n.child1 = topo.child1[i]; n.pad0 = n.pad1 = 0;
+    levelRanges.clear();
+    const auto tBuild0 = std::chrono::steady_clock::now();
+    if (nr < 2 || lbvhOnHost) {
+      std::vector<float> boxes(domain.n);
+      HIP_TRY(this, hipMemcpy(boxes.data(), domain.p, domain.n * sizeof(float), hipMemcpyDeviceToHost));
+      LbvhTopology topo;
+      topo.build(boxes.data(), nr);
+      boxes.clear(); boxes.shrink_to_fit();
+      const size_t ni = topo.child0.size();
+      std::vector<BvhNode> tmpl(ni);
+      for (size_t i = 0; i < ni; i++) {
+        BvhNode &n = tmpl[i];
+        n.q0 = make_float4(FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX);
+        n.q1 = make_float4(-FLT_MAX, -FLT_MAX, FLT_MAX, FLT_MAX);
+        n.q2 = make_float4(FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX);
+        n.child0 = topo.child0[i]; n.child1 = topo.child1[i]; n.pad0 = n.pad1 = 0;
+      }
+      HIP_TRY(this, topoNodes.upload(tmpl.data(), ni));
+      int maxH = 0;
+      for (size_t i = 0; i < ni; i++) maxH = std::max(maxH, topo.height[i]);
+      std::vector<int> count(maxH + 2, 0);
+      for (size_t i = 0; i < ni; i++) count[topo.height[i]]++;
+      std::vector<int> begin(1, 0);
+      for (int hh = 1; hh <= maxH; hh++) begin.push_back(begin.back() + count[hh]);
+      std::vector<int32_t> ids(ni);
+      {
+        std::vector<int> cursor(begin.begin(), begin.end());
+        for (size_t i = 0; i < ni; i++) ids[cursor[topo.height[i] - 1]++] = (int32_t)i;
+      }
+      for (int hh = 1; hh <= maxH; hh++) levelRanges.push_back({ begin[hh - 1], count[hh] });   // by height, leaves' parents first
+      HIP_TRY(this, levelIds.upload(ids.data(), ids.size()));
+      sc.numInternal = (uint32_t)ni;
+    } else {
+      const size_t ni = nr - 1;
+      HIP_TRY(this, topoNodes.alloc(ni));
+      HIP_TRY(this, levelIds.alloc(ni));
+      std::vector<uint32_t> perDepth;
+      HIP_TRY(this, buildLbvhTopologyDevice(domain.p, (uint32_t)nr, topoNodes.p, levelIds.p, perDepth, nullptr));
+      int at = 0;
+      std::vector<std::pair<int, int>> byDepth;
+      for (uint32_t c : perDepth) { byDepth.push_back({ at, (int)c }); at += (int)c; }
+      levelRanges.assign(byDepth.rbegin(), byDepth.rend());            // deepest level first
+      sc.numInternal = (uint32_t)ni;
     }
-    HIP_TRY(this, volNodes.upload(topoTemplate.data(), ni));
-    int maxH = 0;
-    for (size_t i = 0; i < ni; i++) maxH = std::max(maxH, topo.height[i]);
-    std::vector<int> count(maxH + 2, 0);
-    for (size_t i = 0; i < ni; i++) count[topo.height[i]]++;
-    levelBegin.assign(1, 0);
-    for (int hh = 1; hh <= maxH; hh++) levelBegin.push_back(levelBegin.back() + count[hh]);
-    std::vector<int32_t> ids(ni);
-    {
-      std::vector<int> cursor(levelBegin.begin(), levelBegin.end());
-      for (size_t i = 0; i < ni; i++) ids[cursor[topo.height[i] - 1]++] = (int32_t)i;
-    }
-    HIP_TRY(this, levelIds.upload(ids.data(), ids.size()));
-    sc.numInternal = (uint32_t)ni;
+    HIP_TRY(this, volNodes.alloc(topoNodes.n));
+    HIP_TRY(this, hipMemcpy(volNodes.p, topoNodes.p, topoNodes.n * sizeof(BvhNode), hipMemcpyDeviceToDevice));
     lbvhBuilt = true;
     volDirty = isoDirty = true;          // boxes of both LBVHs come from the next refit
+    if (std::getenv("EXA_HIP_VERBOSE")) {
+      (void)hipDeviceSynchronize();
+      std::fprintf(stderr, "[exa_hip] LBVH over %zu regions built on the %s in %.1f ms (%zu refit launches)\n", nr,
+                   (nr < 2 || lbvhOnHost) ? "host" : "device",
+                   std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBuild0).count(), levelRanges.size());
+    }
     return 0;
   }
   bool needLbvh() const { return !useKd() || (haveTracer && tracer.enabled); }
 
   int refit(DevBuf<BvhNode> &nodes, const uint8_t *active, hipStream_t s)
   {
-    for (size_t h = 0; h + 1 < levelBegin.size(); h++) {
-      const int cnt = levelBegin[h + 1] - levelBegin[h];
-      HIP_TRY(this, launchRefit(nodes.p, levelIds.p + levelBegin[h], cnt, domain.p, active, s));
-    }
+    for (const auto &r : levelRanges)
+      HIP_TRY(this, launchRefit(nodes.p, levelIds.p + r.first, r.second, domain.p, active, s));
     return 0;
   }
 
@@ -570,8 +595,10 @@ struct ExaHipRenderer {
         volDirty = false;
       }
       if (needIso && isoDirty) {            // needIsoBVHRebuild (OptixRenderer.cpp:539-543)
-        if (lbvhBuilt && !isoNodes.p && !topoTemplate.empty())
-          HIP_TRY(this, isoNodes.upload(topoTemplate.data(), topoTemplate.size()));
+        if (lbvhBuilt && !isoNodes.p && topoNodes.n) {
+          HIP_TRY(this, isoNodes.alloc(topoNodes.n));
+          HIP_TRY(this, hipMemcpyAsync(isoNodes.p, topoNodes.p, topoNodes.n * sizeof(BvhNode), hipMemcpyDeviceToDevice, s));
+        }
         HIP_TRY(this, launchIsoActivity(sc, fs, isoActive.p, s));
         if (lbvhBuilt && refit(isoNodes, isoActive.p, s)) return 1;
         if (haveKd && kdRefit(isoActive.p, 1, s)) return 1;
@@ -1272,6 +1299,10 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
+  if (!std::strcmp(key, "lbvh_build")) {              // 0 = on the device (default), 1 = on the host; before the first LBVH frame
+    if (h->lbvhBuilt && value != h->lbvhOnHost) { h->fail("exa_hip_set_option: lbvh_build must be set before the LBVH is first used"); return 1; }
+    h->lbvhOnHost = value; return 0;
+  }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
   if (!std::strcmp(key, "tf_filter")) {
     if (value != 0 && value != 1) { h->fail("exa_hip_set_option: tf_filter is 0 or 1"); return 1; }

@@ -167,6 +167,27 @@ def test_tf_filter_fixed_point_weight_matches_oracle_in_both_modes(accel):
     R.close()
 
 
+@pytest.mark.parametrize("name", ["ex0", "ex2", "ex3_iso", "amr_grad", "amr_iso", "amr_2ch", "gen_exajet", "c4_small"])
+def test_device_built_lbvh_is_the_host_built_tree(name):
+    """accel=0 walks a software LBVH over the regions.  It is built on the device (Morton codes, radix sort, topology
+    level by level; option lbvh_build=0, default); lbvh_build=1 builds it on the host.  Same codes, same split rule,
+    same node numbering: identical frames, identical node fetches, and both equal the kd walk's frame."""
+    if name == "c4_small":
+        case = Case(scenes.config("c4_exajet", scale=0.2), W=512, H=512, grad=1, xf_domains=[(0.0, 1.0)])
+    else:
+        case = CASES[name]()
+    case.accel, case.fast_math = 0, 0
+    out = {}
+    for where in (0, 1):
+        case.options = {"lbvh_build": where}
+        out[where] = case.run_hip(stats=True)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    assert out[0][2]["nodes_visited"] == out[1][2]["nodes_visited"] > 0
+    case.accel, case.options = 1, {}
+    kd = case.run_hip()
+    assert np.array_equal(kd[1].view(np.uint32), out[0][1].view(np.uint32))
+
+
 def test_ao_rays_match_up_to_trig_ulps():
     # AO directions go through cosf/sinf (libm vs OCML differ by an ulp); a hit/miss flip moves a
     # pixel by 1/2 of its surface colour, so allow a handful of flipped pixels and nothing else
