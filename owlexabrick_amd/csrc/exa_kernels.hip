@@ -85,6 +85,10 @@ template <bool FAST> __device__ __forceinline__ float fsqrt(float a) { return FA
 
 struct Ray { V3 org, dir; float tmin, tmax; };
 
+// "does any active lane want this": the compare's lane mask tested directly (v_cmp + s_cmp); HIP's anyLane() first
+// turns the flag into a register value and compares that again
+__device__ __forceinline__ bool anyLane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
 // exabrick.cu:1588,1703-1707: the viewer's clock heat map — red = clockScale * (cycles this ray's program ran) / 1e6.
 // The start stamp is wave-uniform and stays in scalar registers; with a surfaces pre-pass only the march is timed.
 __device__ __forceinline__ float clockHeat(float clockScale, unsigned long long clockBegin)
@@ -1335,11 +1339,11 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
     if (seg >= (1 << 22)) { C.guardTripped = true; break; }
     // wave-wide refill burst, as in the DVR loop: when one lane has run dry every lane still in this
     // loop advances its own walk while it has a free queue slot
-    if (__any(w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
+    if (anyLane(w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
       for (int g = 0;; g++) {
         if (g >= (1 << 24)) { C.guardTripped = true; w.ref = EXA_KD_DONE; break; }
         const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
-        if (!__any(want)) break;
+        if (!anyLane(want)) break;
         if (want) kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale, a.kdNodes, a.kdRoot);
       }
     }
@@ -1641,11 +1645,11 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
       if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
       // ---- refill burst: as soon as one lane of the wave has run dry, every lane with a
       //      free queue slot advances its own walk (all lanes of the wave take part) ----
-      if (__any(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
+      if (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
         C.lap(ST_T_WALK);
         for (;;) {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
-          if (!__any(want)) break;
+          if (!anyLane(want)) break;
           if (want) kdStep<false, STATS, SMALL>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
         }
       }
@@ -1970,7 +1974,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       for (unsigned g = 0;; g++) {
         if (g == 0xfffffff0u) { C.guardTripped = true; break; }
         const bool want = w.ref != EXA_KD_DONE && myCount < kWideSegCap;
-        if (!__any(want)) break;
+        if (!anyLane(want)) break;
         if (want) kdCollectStep(C, w, winLo, winHi, a, stackF, ray, a.kdMarchNodes, a.kdMarchRoot, mySegs, myCount);
       }
     }

@@ -10,14 +10,17 @@ import sys
 
 out, key = sys.argv[1], sys.argv[2]
 txt = open(os.path.join(out, "summary.txt")).read()
-blk = [b for b in txt.split("== ") if b.startswith("void exa::renderFrame") and (", false>" in b.split("\n")[0] or ", 0>" in b.split("\n")[0])][0]
+# the shipped march: STATS template argument 0 (the last-but-one argument since round 2, the last before)
+blk = [b for b in txt.split("== ") if b.startswith("void exa::renderFrame") and re.search(r", 0(, (true|false))?>", b.split("\n")[0])][0]
 fetch = float(re.search(r"FETCH_SIZE\s+([0-9.e+]+)", blk).group(1))
 write = float(re.search(r"WRITE_SIZE\s+([0-9.e+]+)", blk).group(1))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(root, "profiles", "hbm_traffic.json")
 d = json.load(open(path)) if os.path.exists(path) else {}
 d[key] = (2 * fetch + write) * 1024
-d[key + ":note"] = f"2*FETCH_SIZE({fetch:.6g} KiB)+WRITE_SIZE({write:.6g} KiB), from {os.path.basename(out)}"
+commit = sys.argv[3] if len(sys.argv) > 3 else "?"
+d[key + ":note"] = (f"2*FETCH_SIZE({fetch:.6g} KiB)+WRITE_SIZE({write:.6g} KiB), rocprofv3 --pmc passes of tools/pmc_run.sh "
+                    f"({os.path.basename(out.rstrip('/'))}), kernels of commit {commit}")
 m = re.search(r"SQ_INSTS_VALU\s+([0-9.e+]+)", blk)
 if m:
     d[key + ":valu_wave_instructions"] = float(m.group(1))
