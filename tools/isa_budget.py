@@ -2,7 +2,7 @@
 """Instruction budget of one kernel from source-annotated device assembly.
 
   hipcc --offload-arch=gfx950 <flags of csrc/Makefile> --cuda-device-only -S -gline-tables-only exa_kernels.hip -o annot.s
-  python tools/isa_budget.py annot.s <mangled kernel name> [--blocks]
+  python tools/isa_budget.py annot.s <mangled kernel name> [source.hip]
 
 Every instruction is attributed to the source line of the nearest preceding `.loc` (the line of the innermost inlined
 frame), source lines are mapped to the phases of the kd march (brick visit / sample epilogue / kd walk step / segment
@@ -13,8 +13,11 @@ import re
 import sys
 
 path, kernel = sys.argv[1], sys.argv[2]
-src = open(path.replace("annot.s", "exa_kernels.hip") if len(sys.argv) > 3 and not sys.argv[3].startswith("--") else
-           __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "..", "owlexabrick_amd", "csrc", "exa_kernels.hip")).read().split("\n")
+# the source the assembly was compiled from (line numbers must match); default: the tree's exa_kernels.hip
+import os
+src_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "owlexabrick_amd",
+                                                               "csrc", "exa_kernels.hip")
+src = open(src_path).read().split("\n")
 
 # source line -> enclosing top-level device function (crude: last line at column 0 that opens a function)
 func_of_line = {}
