@@ -63,7 +63,14 @@ struct DeviceScene {
   uint32_t numInternal;            // internal LBVH nodes
 };
 
-enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = 4, kSegQueue = 4,
+#ifndef EXA_KD_STACK
+#define EXA_KD_STACK 3      // per-lane short stack of the kd walk (LDS, 12 B per entry) ...
+#endif
+#ifndef EXA_SEG_QUEUE
+#define EXA_SEG_QUEUE 5     // ... and per-lane queue of accepted segments (12 B per entry): 96 B per lane = 6 workgroups per CU.
+                            // Measured on C4 (stack/queue): 4/4 24.62 ms, 3/5 24.25, 2/6 25.11, 5/3 25.44, 6/2 27.82
+#endif
+enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kSegQueue = EXA_SEG_QUEUE,
        kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
        kWideSegCap = 256 };   // wide march: leaves a window walker lists per round (16 B each; a fuller window takes more rounds)
 

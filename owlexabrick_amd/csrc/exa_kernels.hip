@@ -17,6 +17,7 @@
 //   FHDR    march header carries float(lower) and 2^-level: no conversions / exponent build per visit; the -1 clamp
 //           of the cell index is done on the float
 //   DTPOW2  first sample of a segment: x / dt as x * (1/dt) when dt is a power of two (exact)
+//   MED3    clamp(l, 0, size-1) as one v_med3_i32
 #ifndef EXA_OPT_POP1
 #define EXA_OPT_POP1 1
 #endif
@@ -31,6 +32,9 @@
 #endif
 #ifndef EXA_OPT_DTPOW2
 #define EXA_OPT_DTPOW2 1
+#endif
+#ifndef EXA_OPT_MED3
+#define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
 #endif
 
 namespace exa {
@@ -362,10 +366,20 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const bool vlx = (uint32_t)lx < (uint32_t)sx, vhx = hx < sx;
   const bool vly = (uint32_t)ly < (uint32_t)sy, vhy = hy < sy;
   const bool vlz = (uint32_t)lz < (uint32_t)sz, vhz = hz < sz;
+#if EXA_OPT_MED3
+  // clamp(l, 0, size-1) as one v_med3_i32 (sizes >= 1, so 0 <= size-1 and the median IS the clamp); the compiler
+  // cannot prove the bound order and emits v_max + v_min
+  auto med3 = [](int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+  const int cxl = med3(lx, 0, sx - 1), cxh = min(hx, sx - 1);
+  const int cyl = med3(ly, 0, sy - 1), cyh = min(hy, sy - 1);
+  const int czl = med3(lz, 0, sz - 1), czh = min(hz, sz - 1);
+  const int bx = med3(lx, 0, max(sx - 2, 0));
+#else
   const int cxl = min(max(lx, 0), sx - 1), cxh = min(hx, sx - 1);
   const int cyl = min(max(ly, 0), sy - 1), cyh = min(hy, sy - 1);
   const int czl = min(max(lz, 0), sz - 1), czh = min(hz, sz - 1);
   const int bx = min(max(lx, 0), max(sx - 2, 0));
+#endif
   uint32_t rowLL, rowHL, rowLH, rowHH;                      // cell index of the pair's first cell, per (y,z) row
   if (EXA_OPT_MUL24 && SMALL) {
     // SMALL: every factor below 2^24 and every product below 2^32 (checked per scene on the host)

@@ -17,6 +17,7 @@ if [ "$mode" = build ]; then
     (
       d="$OUT/obj_$name"; mkdir -p "$d"
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c "$CS/exa_kernels.hip" -o "$d/exa_kernels.o" &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c "$CS/exa_lbvh.hip" -o "$d/exa_lbvh.o" &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -x hip -c "$CS/exa_module.cpp" -o "$d/exa_module.o" &&
       /opt/rocm/bin/hipcc $FLAGS -c "$CS/exa_prep.cpp" -o "$d/exa_prep.o" &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$LIBS/libexa_hip_$name.so" "$d"/*.o -lpthread &&
