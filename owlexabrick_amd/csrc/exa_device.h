@@ -64,11 +64,12 @@ struct DeviceScene {
 };
 
 #ifndef EXA_KD_STACK
-#define EXA_KD_STACK 3      // per-lane short stack of the kd walk (LDS, 12 B per entry) ...
+#define EXA_KD_STACK 4      // per-lane short stack of the kd walk (LDS, 12 B per entry) ...
 #endif
 #ifndef EXA_SEG_QUEUE
-#define EXA_SEG_QUEUE 5     // ... and per-lane queue of accepted segments (12 B per entry): 96 B per lane = 6 workgroups per CU.
-                            // Measured on C4 (stack/queue): 4/4 24.62 ms, 3/5 24.25, 2/6 25.11, 5/3 25.44, 6/2 27.82
+#define EXA_SEG_QUEUE 4     // ... and per-lane queue of accepted segments (12 B per entry): 96 B per lane = 6 workgroups per CU.
+                            // Measured on C4 (stack/queue), bursts that end when no lane is dry: 4/4 22.42 ms, 3/5 22.56,
+                            // 5/3 22.89, 2/6 23.41 (with bursts run until every queue is full: 4/4 24.62, 3/5 24.25)
 #endif
 enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kSegQueue = EXA_SEG_QUEUE,
        kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)

@@ -1357,8 +1357,8 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
       for (int g = 0;; g++) {
         if (g >= (1 << 24)) { C.guardTripped = true; w.ref = EXA_KD_DONE; break; }
         const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
-        if (!anyLane(want)) break;
         if (want) kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale, a.kdNodes, a.kdRoot);
+        if (!anyLane(w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) break;     // no lane is dry any more
       }
     }
     const int qc = w.pk.get(PK_QCOUNT);
@@ -1657,15 +1657,15 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel
     unsigned iter = 0;
     for (;; iter++) {
       if (iter == 0xfffffff0u) { C.guardTripped = true; break; }
-      // ---- refill burst: as soon as one lane of the wave has run dry, every lane with a
-      //      free queue slot advances its own walk (all lanes of the wave take part) ----
+      // ---- refill burst: while a lane of the wave is dry (no segment, empty queue, walk not finished), every lane
+      //      with a free queue slot advances its own walk; the burst ends as soon as no lane is dry any more —
+      //      running it until every queue is full dragged it out with a handful of lanes (C4: 24.1 -> 22.5 ms) ----
       if (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
         C.lap(ST_T_WALK);
-        for (;;) {
+        do {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
-          if (!anyLane(want)) break;
           if (want) kdStep<false, STATS, SMALL>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
-        }
+        } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
       }
       if (!haveSeg) {
         // ---- next segment from this lane's queue ----
