@@ -2187,6 +2187,8 @@ hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay
   const bool small = a.mul24 && a.addr32;                   // 24-bit address multiplies and 32-bit byte offsets are valid
 #define EXA_W4(G, F, S, L) do { if (small) hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, L, true>), grid, block, lds, s, a); \
                                 else hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, L, false>), grid, block, lds, s, a); } while (0)
+  // 8 lanes per ray were measured and are not instantiated: on the critical-path probe (tests/gpu_wide_probe.py, C4,
+  // rank 0 of 64) 1 / 2 / 4 / 8 lanes take 4.71 / 3.37 / 2.52 / 3.00 ms
 #define EXA_W3(G, F, S) do { if (lanesPerRay == 2) EXA_W4(G, F, S, 2); else EXA_W4(G, F, S, 4); } while (0)
 #define EXA_W2(G, F) do { if (surf) EXA_W3(G, F, true); else EXA_W3(G, F, false); } while (0)
   if (grad) { if (fast) EXA_W2(true, true); else EXA_W2(true, false); }

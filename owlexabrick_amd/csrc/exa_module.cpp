@@ -18,6 +18,17 @@
 
 using namespace exa;
 
+// calibration of the wide-march assignment (assignWide), overridable for A/B builds
+#ifndef EXA_WIDE_SPEED2
+#define EXA_WIDE_SPEED2 1.63
+#endif
+#ifndef EXA_WIDE_WORK2
+#define EXA_WIDE_WORK2 1.49
+#endif
+#ifndef EXA_WIDE_WORK4
+#define EXA_WIDE_WORK4 1.88
+#endif
+
 namespace {
 
 thread_local std::string g_createError;
@@ -435,9 +446,15 @@ struct ExaHipRenderer {
     if (wideMode == 2 || wideMode == 4) {
       (wideMode == 4 ? w4 : w2) = curMap;
     } else if (wideMode == 1 && costOfTile) {
-      // measured on C4 / MI355X: a critical tile finishes 1.63x / 2.36x sooner with 2 / 4 lanes per
-      // ray and costs 1.49x / 1.88x the work; a loaded GPU steps a wave 1.3x slower
-      const double kSpeed2 = 1.63, kWork2 = 1.49, kWork4 = 1.88, kLoaded = 1.3;
+      // Model constants: a critical tile finishes kSpeed2 (2 lanes) times sooner and costs kWork2 / kWork4
+      // times the work; a loaded GPU steps a wave 1.3x slower.  Measured with the round-1 kernels (probe 6.0 -> 3.7 ->
+      // 2.5 ms).  With the round-2 kernels the probe (tests/gpu_wide_probe.py) gives 4.78 -> 3.39 -> 2.52 ms (8 lanes:
+      // 3.00 ms, not instantiated) and every tile of a rank forced wide costs x1.9 / x2.4 the time (tests/gpu_shard_modes.py);
+      // variations of the constants around these values move the shard of 8 by +-0.2 ms (4.46 .. 4.95 ms), the set below
+      // stays within 0.05 ms of the best one tried.
+      // NOTE: the module owns exactly three side streams.  A fourth (tried for an 8-lane class) made two of the
+      // streams that carry one frame's launches share a hardware queue, and the shard of 8 went from 4.6 to 7.0 ms.
+      const double kSpeed2 = EXA_WIDE_SPEED2, kWork2 = EXA_WIDE_WORK2, kWork4 = EXA_WIDE_WORK4, kLoaded = 1.3;
       double fill = 0;
       for (size_t b = 0; b < n; b++) fill += 4.0 * (*costOfTile)[curMap[b]];
       fill *= kLoaded / numSimdWaves;
