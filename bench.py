@@ -61,6 +61,12 @@ def effective_cpus():
     return n
 
 
+# HIP maps streams onto a few hardware queues (default 4).  One frame's launches go to up to three side streams of the
+# module plus the caller's stream; bench adds a communication stream and RCCL its own.  Two of the march streams on one
+# hardware queue serialise the frame's kernels (measured: a shard of 8 went from 4.6 to 7.0 ms), so ask for more queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def spawn_ranks(n):
     """`bench.py --gpus N` without a launcher: start N fresh rank processes and wait for them.  Called before this
     process has imported torch or made any GPU call; the children are new interpreters (never an exec of a process
@@ -215,7 +221,11 @@ def main():
     for kv in args.option:
         k, v = kv.split("=")
         R.setOption(k, int(v))
-    R.setShard(rank, world)
+    # EXA_BENCH_SHARD="r,w" (with EXA_BENCH_FORCE_DIST=1 on a one-GPU box): this single rank renders what rank r of a
+    # w-GPU job renders and sends its shard through the process group — a rehearsal of one rank's per-frame work
+    rehearse = os.environ.get("EXA_BENCH_SHARD") if world == 1 else None
+    shard_rank, shard_world = (int(x) for x in rehearse.split(",")) if rehearse else (rank, world)
+    R.setShard(shard_rank, shard_world)
     R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
     R.updateXF(0, xf[:, 3], xf[:, :3], scene.value_range, 1.0)
     for c in range(1, len(scene.fields)):
@@ -231,19 +241,17 @@ def main():
     R.updateFrameID(0)
 
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
-    stride = ((tiles + world - 1) // world) * 256 if world > 1 else W * H      # a 1-rank "shard" is the row-major frame
+    stride = ((tiles + shard_world - 1) // shard_world) * 256 if shard_world > 1 else W * H   # a 1-rank "shard" is the row-major frame
     # Two shard buffers: while the shard of frame k travels to rank 0, frame k+1 is already being marched into the
     # other one (the accumulation buffer is not read at frameID 0, and with spp > 1 the gather waits for the last
     # sample anyway).  EXA_BENCH_PIPELINE=0 keeps every frame synchronous, like owlLaunch2D.
     pipelined = use_dist and backend == "nccl" and os.environ.get("EXA_BENCH_PIPELINE", "1") != "0"
     shards = [torch.zeros(stride, dtype=torch.int32, device=dev) for _ in range(2 if pipelined else 1)]
-    final = torch.zeros(W * H, dtype=torch.int32, device=dev) if (use_dist and rank == 0) else None
+    final = torch.zeros(W * H if not rehearse else stride, dtype=torch.int32, device=dev) if (use_dist and rank == 0) else None
     # rank 0 receives every shard straight into its slice of one flat buffer (no concatenation step)
     gathered_flat = torch.zeros(stride * world, dtype=torch.int32, device=dev) if (use_dist and rank == 0) else None
     gathered = list(gathered_flat.chunk(world)) if gathered_flat is not None else None
-    render_stream = torch.cuda.Stream(device=dev) if pipelined else None
     comm_stream = torch.cuda.Stream(device=dev) if pipelined else None
-    rendered = [torch.cuda.Event() for _ in shards]
     consumed = [torch.cuda.Event() for _ in shards]
     frame_no = [0]
 
@@ -276,16 +284,18 @@ def main():
             if rank == 0:
                 untile(stream)
             return
-        # pipelined: the march goes to the render stream and returns at once; the gather + untile of this frame are
-        # queued on the communication stream behind it and overlap the next frame's march
-        render_stream.wait_event(consumed[k])                              # the buffer's previous gather is done
+        # pipelined: the host waits for this frame's march (synchronous render, like owlLaunch2D), hands the shard to the
+        # communication stream and starts the next frame's march at once: the gather + untile of frame k run while
+        # frame k+1 is marched.  (Queuing the march itself ahead of time was measured and is slower: a frame with wide
+        # tiles forks over three streams, and resolving those cross-queue dependencies on the device instead of on the
+        # host cost 0.9 ms per frame on a shard of 8 — 5.5 instead of 4.6 ms.)
+        consumed[k].synchronize()                                          # the buffer's previous gather is done (long ago)
+        stream = torch.cuda.current_stream().cuda_stream
         for f in range(args.spp):
             if args.spp > 1:
                 R.updateFrameID(f)
-            R.render(device_ptr=shard.data_ptr(), stream=render_stream.cuda_stream, async_=True)
-        rendered[k].record(render_stream)
+            R.render(device_ptr=shard.data_ptr(), stream=stream)
         with torch.cuda.stream(comm_stream):
-            comm_stream.wait_event(rendered[k])
             dist.gather(shard, gathered, dst=0)
             if rank == 0:
                 untile(comm_stream.cuda_stream)
@@ -309,8 +319,7 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        if not pipelined:
-            kernel_ms.append(R.stats()["kernel_ms"])       # the step's last launch
+        kernel_ms.append(R.stats()["kernel_ms"])           # the step's last launch (HIP events on the launch stream)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -319,13 +328,6 @@ def main():
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
-    if pipelined:
-        # kernel time per launch (HIP events on the launch stream), measured after the timed region on
-        # synchronous frames: an asynchronous launch's events are not read back inside the loop
-        for _ in range(min(5, max(2, args.steps))):
-            R.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
-            kernel_ms.append(R.stats()["kernel_ms"])
-
     # aggregate per-rank work counters and kernel time
     agg = torch.tensor([st["samples"], st["brick_visits"], st["corner_loads"], st["segments"], st["nodes_visited"],
                         st["pixels"]], dtype=torch.float64, device=cdev)
@@ -346,6 +348,7 @@ def main():
                       f"{', %d spp' % args.spp if args.spp > 1 else ''}, {args.config.split('_', 1)[1]}-like, MI355X",
             "value": fps, "unit": "frames/s",
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
+            **({"rehearsal_of": f"rank {shard_rank} of a {shard_world}-GPU job, on one GPU; value is this rank's frame rate"} if rehearse else {}),
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "msamples_per_s": samples_total / 1e6 * fps * args.spp,
