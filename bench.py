@@ -122,6 +122,12 @@ def main():
     ap.add_argument("--spp", type=int, default=1, help="frames accumulated per step (frameID 0..spp-1); a step is one converged frame")
     ap.add_argument("--dump", default=None, help="write the frame as PNG (rank 0)")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=INT", help="exa_hip_set_option (tuning knobs)")
+    ap.add_argument("--in-flight", type=int, default=int(os.environ.get("EXA_BENCH_IN_FLIGHT", "0")),
+                    help="frames in flight: F > 1 renders consecutive frames with F renderer handles on F streams, so that "
+                         "the tail of one frame (its longest rays) overlaps the bulk of the next; every frame is complete "
+                         "and gathered, frame k+F waits for frame k.  0 = default: 1 on one GPU (the GPU is full anyway, "
+                         "+1 %), 3 on a shard of several GPUs, where a rank's frame does not fill its GPU (rank 0 of 8 "
+                         "rehearsed: 4.6 -> 2.9 ms per frame)")
     ap.add_argument("--spawn-check", action="store_true",
                     help="every rank prints its RANK/WORLD_SIZE/MASTER_* as one JSON line and exits (no GPU; tests)")
     args = ap.parse_args()
@@ -206,39 +212,50 @@ def main():
     t0 = time.time()
     prep = binding.Prep(scene, num_threads=host_threads)
     t_prep = time.time() - t0
-    t0 = time.time()
-    R = binding.Renderer(prep, device=local_rank)
-    t_up = time.time() - t0
-    log(f"prep {t_prep:.1f}s ({prep.scene.numRegions} regions, {prep.scene.leafListSize} leaf entries), "
-        f"upload {t_up:.1f}s")
-
     lo, hi = prep.voxel_bounds()
     cam = harness.default_camera(lo, hi, W, H)                 # exa/viewer.cpp:1289-1294
     xf = harness.default_xf()
-    R.resizeFrameBuffer((W, H))
-    R.setOption("tile_order", args.tile_order)
-    R.setOption("accel", args.accel)
-    for kv in args.option:
-        k, v = kv.split("=")
-        R.setOption(k, int(v))
     # EXA_BENCH_SHARD="r,w" (with EXA_BENCH_FORCE_DIST=1 on a one-GPU box): this single rank renders what rank r of a
     # w-GPU job renders and sends its shard through the process group — a rehearsal of one rank's per-frame work
     rehearse = os.environ.get("EXA_BENCH_SHARD") if world == 1 else None
     shard_rank, shard_world = (int(x) for x in rehearse.split(",")) if rehearse else (rank, world)
-    R.setShard(shard_rank, shard_world)
-    R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
-    R.updateXF(0, xf[:, 3], xf[:, :3], scene.value_range, 1.0)
-    for c in range(1, len(scene.fields)):
-        R.updateXF(c, xf[:, 3], xf[:, :3], (0.0, 1.0), 1.0)
-    if args.iso is not None:
-        R.updateIsoValues([args.iso, 0], [0, 0], [1, 0])
-    else:
-        R.updateIsoValues([0, 0], [0, 0], [0, 0])
-    R.setSpaceSkipping(True)
-    R.setGradientShadingDVR(not args.no_grad)
-    R.updateDt(0.5)
-    R.frameState.ao.enabled = 1 if args.ao else 0
-    R.updateFrameID(0)
+
+    F = args.in_flight if args.in_flight > 0 else (3 if shard_world > 1 else 1)
+
+    def make_renderer():
+        R = binding.Renderer(prep, device=local_rank)
+        R.resizeFrameBuffer((W, H))
+        R.setOption("tile_order", args.tile_order)
+        R.setOption("accel", args.accel)
+        if F > 1:
+            # the wide march shortens a lone frame's critical path at the price of extra work; with frames in flight
+            # the next frame fills the GPU instead and the extra work only costs (rank 0 of 8: 2.9 vs 4.6 ms per frame)
+            R.setOption("wide_march", 0)
+        for kv in args.option:
+            k, v = kv.split("=")
+            R.setOption(k, int(v))
+        R.setShard(shard_rank, shard_world)
+        R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
+        R.updateXF(0, xf[:, 3], xf[:, :3], scene.value_range, 1.0)
+        for c in range(1, len(scene.fields)):
+            R.updateXF(c, xf[:, 3], xf[:, :3], (0.0, 1.0), 1.0)
+        if args.iso is not None:
+            R.updateIsoValues([args.iso, 0], [0, 0], [1, 0])
+        else:
+            R.updateIsoValues([0, 0], [0, 0], [0, 0])
+        R.setSpaceSkipping(True)
+        R.setGradientShadingDVR(not args.no_grad)
+        R.updateDt(0.5)
+        R.frameState.ao.enabled = 1 if args.ao else 0
+        R.updateFrameID(0)
+        return R
+
+    t0 = time.time()
+    Rs = [make_renderer() for _ in range(F)]       # F > 1: one handle (scene copy, accumulation buffer, streams) per frame in flight
+    R = Rs[0]
+    t_up = time.time() - t0
+    log(f"prep {t_prep:.1f}s ({prep.scene.numRegions} regions, {prep.scene.leafListSize} leaf entries), "
+        f"upload {t_up:.1f}s ({F} handle(s))")
 
     tiles = ((W + 15) // 16) * ((H + 15) // 16)
     stride = ((tiles + shard_world - 1) // shard_world) * 256 if shard_world > 1 else W * H   # a 1-rank "shard" is the row-major frame
@@ -246,13 +263,15 @@ def main():
     # other one (the accumulation buffer is not read at frameID 0, and with spp > 1 the gather waits for the last
     # sample anyway).  EXA_BENCH_PIPELINE=0 keeps every frame synchronous, like owlLaunch2D.
     pipelined = use_dist and backend == "nccl" and os.environ.get("EXA_BENCH_PIPELINE", "1") != "0"
-    shards = [torch.zeros(stride, dtype=torch.int32, device=dev) for _ in range(2 if pipelined else 1)]
+    shards = [torch.zeros(stride, dtype=torch.int32, device=dev) for _ in range(max(F, 2 if pipelined else 1))]
     final = torch.zeros(W * H if not rehearse else stride, dtype=torch.int32, device=dev) if (use_dist and rank == 0) else None
     # rank 0 receives every shard straight into its slice of one flat buffer (no concatenation step)
     gathered_flat = torch.zeros(stride * world, dtype=torch.int32, device=dev) if (use_dist and rank == 0) else None
     gathered = list(gathered_flat.chunk(world)) if gathered_flat is not None else None
-    comm_stream = torch.cuda.Stream(device=dev) if pipelined else None
+    comm_stream = torch.cuda.Stream(device=dev) if (pipelined or (F > 1 and use_dist)) else None
     consumed = [torch.cuda.Event() for _ in shards]
+    march_streams = [torch.cuda.Stream(device=dev) for _ in range(F)] if F > 1 else None
+    rendered = [torch.cuda.Event() for _ in shards]
     frame_no = [0]
 
     def untile(stream_handle):
@@ -265,6 +284,34 @@ def main():
         k = frame_no[0] % len(shards)
         frame_no[0] += 1
         shard = shards[k]
+        if F > 1:
+            # F frames in flight: frame k goes to handle k % F on that handle's stream and the call returns at once;
+            # the host only waits for frame k - F (its shard gathered), so the GPU always holds the tail of one frame
+            # and the bulk of the next
+            consumed[k].synchronize()
+            Rk, st_k = Rs[k], march_streams[k]
+            for f in range(args.spp):
+                if args.spp > 1:
+                    Rk.updateFrameID(f)
+                Rk.render(device_ptr=shard.data_ptr(), stream=st_k.cuda_stream, async_=True)
+            if not use_dist:
+                consumed[k].record(st_k)
+                return
+            rendered[k].record(st_k)
+            with torch.cuda.stream(comm_stream):
+                comm_stream.wait_event(rendered[k])
+                if backend == "nccl":
+                    dist.gather(shard, gathered, dst=0)
+                else:
+                    host = shard.cpu()
+                    hl = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host, hl, dst=0)
+                    if rank == 0:
+                        gathered_flat.copy_(torch.cat(hl))
+                if rank == 0:
+                    untile(comm_stream.cuda_stream)
+                consumed[k].record(comm_stream)
+            return
         if not pipelined:
             stream = torch.cuda.current_stream().cuda_stream
             for f in range(args.spp):                                      # viewer.cpp:279-288, one launch per sample
@@ -307,8 +354,9 @@ def main():
     log("stats:", {k: v for k, v in st.items() if k not in ("kernel_ms", "rebuild_ms")})
     # the first frames are synchronous in every mode: the launch-order feedback measures tile costs on a
     # synchronous frame and re-orders the launch
-    for _ in range(2):
-        R.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    for Rk in Rs:
+        for _ in range(2):
+            Rk.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
 
     for _ in range(args.warmup):
         step()
@@ -319,7 +367,8 @@ def main():
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(R.stats()["kernel_ms"])           # the step's last launch (HIP events on the launch stream)
+        if F == 1:
+            kernel_ms.append(R.stats()["kernel_ms"])       # the step's last launch (HIP events on the launch stream)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -328,6 +377,14 @@ def main():
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    if F > 1:
+        # kernel time per launch (HIP events on the launch stream) on synchronous frames after the timed region: with
+        # several frames in flight a launch shares the GPU with its neighbours and its own duration says little
+        torch.cuda.synchronize()
+        for _ in range(min(5, max(2, args.steps))):
+            R.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+            kernel_ms.append(R.stats()["kernel_ms"])
+
     # aggregate per-rank work counters and kernel time
     agg = torch.tensor([st["samples"], st["brick_visits"], st["corner_loads"], st["segments"], st["nodes_visited"],
                         st["pixels"]], dtype=torch.float64, device=cdev)
@@ -350,12 +407,15 @@ def main():
             "n_gpus": world, "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup,
             **({"rehearsal_of": f"rank {shard_rank} of a {shard_world}-GPU job, on one GPU; value is this rank's frame rate"} if rehearse else {}),
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "frames_in_flight": F,
             "msamples_per_s": samples_total / 1e6 * fps * args.spp,
             "config": {"workload": f"{args.config} (seed {cfg['seed']:#x} procedural AMR, scale {args.scale}): "
                                    f"{scene.num_cells} cells / {scene.bricks7.shape[0]} bricks / "
                                    f"{int(prep.scene.numRegions)} regions, {W}x{H} DVR, dt 0.5, alpha ramp, "
                                    f"gradient shading {'off' if args.no_grad else 'on'}, space skipping on, frameID 0",
+                       "frames_in_flight": (f"{F}: frame k on renderer handle k % {F} (own scene copy, accumulation buffer and stream), "
+                                            f"frame k+{F} waits for frame k; every frame is rendered completely and gathered; "
+                                            f"kernel_ms is a lone frame's launch") if F > 1 else "1 (every frame synchronous)",
                        "tiling": f"16x16 tiles interleaved over {world} GPU(s)"
                                  + (f", {'RCCL (nccl)' if backend == 'nccl' else backend} gather to rank 0"
                                     f"{', overlapped with the next frame' if pipelined else ''}" if use_dist else ""),
@@ -452,7 +512,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    R.close()
+    for Rk in Rs:
+        Rk.close()
 
 
 if __name__ == "__main__":
