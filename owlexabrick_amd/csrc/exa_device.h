@@ -114,6 +114,7 @@ struct RenderArgs {
   int32_t            addr32;        // a scalar field, the march headers and the kd nodes are each below 4 GiB ->
                                     // 32-bit byte offsets from a uniform base
   float              invDtPow2;     // 1/dt when launch.dt is a power of two (exact), else 0
+  int32_t            fastSampler;   // surfaces pre-pass: samplePoint on the march headers with the masked-weight basis
   float              tfFracMagic;   // 2^15: TF filter weight rounded to 8 fractional bits (CUDA tex1D), 0: full precision
   int32_t            numXfChannels;
   int32_t            W, H, tilesX, tilesY;

@@ -112,6 +112,7 @@ struct Ctx {
   int *stack;                  // this thread's LBVH stack column in LDS (stride 256)
   unsigned long long st[ST_COUNT];
   bool guardTripped;
+  bool fastSampler = false;    // samplePoint: masked-weight basis on the march headers (kd kernels) or the literal form
   __device__ __forceinline__ void count(int slot, unsigned long long n = 1) { if (STATS == 1) st[slot] += n; }
   // wave time by phase (instrumented variant): the cycles since the wave's previous mark go to the phase that
   // mark opened; one lane of the active set keeps the books, the mark itself lives in LDS (per wave)
@@ -473,12 +474,24 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
   const float *field = sc.scalars + sc.channelOffset[channel];
   Basis B;
   B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
-  int brickID = ri.firstBrick;
-  for (int child = 0;;) {
-    const int4 b0 = sc.bricks[2 * brickID], b1 = sc.bricks[2 * brickID + 1];
-    addBasisFunctions<DERIV, STATS>(C, B, b0, b1, field, pos);
-    if (++child >= ri.listSize) break;
-    brickID = sc.leafList[ri.listBegin + child];
+  if (C.fastSampler) {
+    // the kd kernels' surfaces pre-pass: march headers along the leaf list and the masked-weight basis evaluation of
+    // the DVR march (bit-identical sums, ~40 % fewer instructions per brick, no brick-id indirection)
+    for (int child = 0; child < ri.listSize; child++) {
+      const unsigned at = 2u * (unsigned)(ri.listBegin + child);
+      const int4 h0 = sc.leafHdr[at], h1 = sc.leafHdr[at + 1u];
+      addBasisFast<DERIV, STATS, false>(C, B, h0, h1, field, pos);
+    }
+  } else {
+    // the LBVH kernel keeps the literal form of addBasisFunctions: an independent evaluation of the same sums, which
+    // the tests compare with the kd kernels bit for bit
+    int brickID = ri.firstBrick;
+    for (int child = 0;;) {
+      const int4 b0 = sc.bricks[2 * brickID], b1 = sc.bricks[2 * brickID + 1];
+      addBasisFunctions<DERIV, STATS>(C, B, b0, b1, field, pos);
+      if (++child >= ri.listSize) break;
+      brickID = sc.leafList[ri.listBegin + child];
+    }
   }
   if (B.sumW <= 1e-20f) return false;
   value = B.sumWV / B.sumW;
@@ -1466,6 +1479,11 @@ __global__ __launch_bounds__(kKdBlock, 3) void surfacePrepassKdKernel(const Rend
   C.xfLds = xfLds;
   C.stack = stackRef + threadIdx.x;
   C.guardTripped = false;
+  // The counting variant keeps the literal sampler: for the NaN positions the iso march produces where a field equals the
+  // iso value over a whole step (tavg = 0/0, exabrick.cu:1047-1053; the reference's NaN guard is at :1088) the two
+  // forms clamp the cell index differently (int(NaN) = 0 vs max(NaN, -1) = -1), which changes nothing in the sums
+  // (NaN either way) but counts other cells as "read".
+  C.fastSampler = a.fastSampler != 0 && STATS != 1;
   if (STATS) for (int i = 0; i < ST_COUNT; i++) C.st[i] = 0;
 
   // a workgroup is kKdBlock/64 waves; each wave renders one 8x8 block of a 16x16 tile

@@ -266,6 +266,7 @@ struct ExaHipRenderer {
   int debugPixel = -1;
   int fastMath = 1;                  // hardware exp2/log2 for the opacity correction (kd kernel)
   int mul24 = 0, addr32 = 0;         // address arithmetic the scene's sizes allow (set at creation)
+  int fastSampler = 1;               // option fast_sampler (surfaces pre-pass; 0 = the literal addBasisFunctions)
   int tfFilter = 1;                  // TF filter weight in 1.8 fixed point as CUDA's tex1D (0: full precision)
   float tfFracMagic() const { return tfFilter ? 32768.f : 0.f; }
   DevBuf<float4> accum;
@@ -691,6 +692,7 @@ struct ExaHipRenderer {
     a.p = p;
     a.xf = xf.p;
     a.tfFracMagic = tfFracMagic();
+    a.fastSampler = fastSampler;
     a.mul24 = mul24; a.addr32 = addr32;
     {
       // launch.dt a power of two (the reference's default 0.5 is): 1/dt is exact and x/dt == x*(1/dt)
@@ -1321,6 +1323,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     h->lbvhOnHost = value; return 0;
   }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
+  if (!std::strcmp(key, "fast_sampler")) { h->fastSampler = value; return 0; }
   if (!std::strcmp(key, "tf_filter")) {
     if (value != 0 && value != 1) { h->fail("exa_hip_set_option: tf_filter is 0 or 1"); return 1; }
     if (value != h->tfFilter) { h->tfFilter = value; h->volDirty = true; }     // region activity goes through the TF lookup
