@@ -249,7 +249,9 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * 0 row-major, 1 row-major 8x8 supertiles per XCD, 2 pseudo-random, 3 centre-out, 4 Z-order
  * (default), 5/6/7 Z-order dealt to the XCDs in chunks of 16/64/256 tiles; "accel" 0 = LBVH with restart per segment,
  * 1 = region kd-tree walked front to back (default when the scene carries one); "lbvh_build" 0 (default) = that LBVH
- * is built on the device (Morton codes, radix sort, topology level by level), 1 = the same tree built on the host; "tile_feedback" 1 (default) = after a
+ * is built on the device (Morton codes, radix sort, topology level by level), 1 = the same tree built on the host;
+ * "fast_sampler" 1 (default) = the surfaces pre-pass of the kd path samples through the march headers with the
+ * masked-weight basis evaluation, 0 = with the literal addBasisFunctions (same sums bit for bit); "tile_feedback" 1 (default) = after a
  * change of view / TF / layout the next synchronous frame records every tile's longest ray and later frames launch
  * the heaviest tiles first (a frame's critical path is its longest rays), 0 = keep the static order; "wide_march" 1
  * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes
