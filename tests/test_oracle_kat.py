@@ -159,6 +159,61 @@ def test_kat2_trilinear_interior_and_shell():
     assert ok and abs(float(v) - float(vol[7, 7, 7])) < 1e-7
 
 
+def _hat_reconstruction(S, region, p):
+    """the basis-function reconstruction of the ExaBrick paper from its definition, independent of the 8-corner
+    bookkeeping of addBasisFunctions (exabrick.cu:620-777): every cell c of every brick overlapping the region carries a
+    hat function H_c(p) = prod_axis max(0, 1 - |p - centre_c| / cellwidth_c); value = sum H_c s_c / sum H_c; the
+    gradient is the reference's un-normalised quotient rule with UNIT-scale derivatives (quirk 3 of SURVEY 8c:
+    d/dx of a hat counts +-1 per cell, not +-1/cellwidth)."""
+    B, R, L, sc = S.bricks(), S.regions()[region], S.leaflist(), S.scalars()
+    sw = swv = 0.0
+    sd, sdc = np.zeros(3), np.zeros(3)
+    for b in L[R["leafListBegin"]:R["leafListBegin"] + R["leafListSize"]]:
+        br = B[b]
+        cw = float(1 << int(br["level"]))
+        sx, sy, sz = (int(v) for v in br["size"])
+        idx = np.arange(sx * sy * sz)
+        cx, cy, cz = idx % sx, (idx // sx) % sy, idx // (sx * sy)
+        ctr = np.stack([cx, cy, cz], axis=1) * cw + np.asarray(br["lower"], dtype=np.float64) + 0.5 * cw
+        u = (np.asarray(p, dtype=np.float64)[None] - ctr) / cw                 # signed distance in cell units
+        h = np.maximum(0.0, 1.0 - np.abs(u))                                   # per-axis hats
+        w = h.prod(axis=1)
+        s = sc[int(br["begin"]) + idx].astype(np.float64)
+        sw += w.sum(); swv += (w * s).sum()
+        for k in range(3):
+            other = np.delete(h, k, axis=1).prod(axis=1)
+            dk = np.where(np.abs(u[:, k]) < 1.0, -np.sign(u[:, k]), 0.0) * other   # unit-scale derivative of the hat
+            sd[k] += (dk * s).sum(); sdc[k] += dk.sum()
+    if sw <= 1e-20:
+        return False, 0.0, np.zeros(3)
+    return True, swv / sw, sw * sd - swv * sdc
+
+
+@pytest.mark.parametrize("scene", ["ex3", "ex4", "amr"])
+def test_sample_point_is_the_hat_basis_reconstruction_across_level_boundaries(scene):
+    """samplePoint / samplePointWithDerivative (exabrick.cu:781-806, 883-928) against the definition of the basis,
+    on regions where bricks of different levels overlap (ex3/ex4: 4^3 level-0 grids next to a 2^3 level-1 grid)"""
+    sc = scenes.example(scene) if scene != "amr" else scenes.amr(seed=3, root=(2, 2, 2), B=4, levels=3)
+    S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    R = S.regions()
+    rng = np.random.default_rng(7)
+    multi = [i for i in range(len(R)) if R[i]["leafListSize"] > 1]
+    assert multi, "scene has no region with overlapping bricks"
+    picks = list(rng.choice(multi, size=min(40, len(multi)), replace=False)) + list(rng.choice(len(R), size=min(20, len(R)), replace=False))
+    checked = 0
+    for r in picks:
+        lo, hi = np.asarray(R[r]["dom_lo"], dtype=np.float64), np.asarray(R[r]["dom_hi"], dtype=np.float64)
+        for p in rng.uniform(lo + 1e-3 * (hi - lo), hi - 1e-3 * (hi - lo), size=(4, 3)):
+            ok, v, g = S.sample_point(int(r), p.astype(np.float32), with_derivative=True)
+            eok, ev, eg = _hat_reconstruction(S, int(r), p.astype(np.float32))
+            assert ok == eok
+            if ok:
+                assert abs(float(v) - ev) <= 2e-5 * max(1.0, abs(ev))
+                assert np.allclose(g, eg, rtol=2e-3, atol=2e-4 * max(1.0, np.abs(eg).max()))
+                checked += 1
+    assert checked > 100
+
+
 def _const_alpha_case(dt, a=0.05, W=24, H=16):
     sc = scenes.artificial(scenes.parse_grids("0 0 0 16 16 16 0  0.5"))
     xf = np.ones((128, 4), dtype=np.float32)
@@ -289,3 +344,103 @@ def test_contour_plane_colour_and_shading():
         assert abs(float(acc[py, px, 1]) - g * abs(float(d[0]))) < 1e-4
         assert acc[py, px, 0] == 0 and acc[py, px, 2] == 0
     assert st["segments"] > 0                    # contour planes switch space skipping off: the volume is still walked
+
+
+def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0):
+    """SURVEY.md Appendix A for a ONE-region, one-brick, level-0 scene without gradient shading, written from the spec
+    in numpy float32 — independent of oracle/exa_oracle.c: LCG jitter, pinhole ray, slab test against the region
+    domain (bounds +- half a cell), first sample at the first (off+i)*dt >= t0, midpoint sampling with partial first
+    and last steps, trilinear hat reconstruction with renormalised partial weights, the published CUDA linear TF
+    filter, opacity correction, front-to-back compositing, termination at 0.98 with the squared-alpha rewrite."""
+    f = np.float32
+    def lcg_init(v0, v1):
+        M, s0 = 0xFFFFFFFF, 0
+        for _ in range(16):
+            s0 = (s0 + 0x9E3779B9) & M
+            v0 = (v0 + ((((v1 << 4) & M) + 0xA341316C) & M ^ ((v1 + s0) & M) ^ (((v1 >> 5) + 0xC8013EA4) & M))) & M
+            v1 = (v1 + ((((v0 << 4) & M) + 0xAD90777D) & M ^ ((v0 + s0) & M) ^ (((v0 >> 5) + 0x7E95761E) & M))) & M
+        return v0
+    state = [lcg_init((frame * W * H + px) & 0xFFFFFFFF, py)]
+    def rnd():
+        state[0] = (1664525 * state[0] + 1013904223) & 0xFFFFFFFF
+        return f((state[0] & 0xFFFFFF) / float(1 << 24))
+    sx_, sy_ = f(px) + rnd(), f(py) + rnd()
+    d = (cam["dir00"] + sx_ * cam["dirDu"]).astype(f)
+    d = (d + sy_ * cam["dirDv"]).astype(f)
+    d = (d * (f(1.0) / np.sqrt(np.dot(d, d).astype(f), dtype=f))).astype(f)
+    o = cam["pos"].astype(f)
+    off = rnd()
+    n = vol.shape[0]
+    lo, hi = f(-0.5), f(n + 0.5)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tl, th = ((lo - o) / d).astype(f), ((hi - o) / d).astype(f)
+    t0 = max(f(1e-6), np.fmax(np.fmax(np.fmin(tl, th)[0], np.fmin(tl, th)[1]), np.fmin(tl, th)[2]))
+    t1 = min(f(1e8), np.fmin(np.fmin(np.fmax(tl, th)[0], np.fmax(tl, th)[1]), np.fmax(tl, th)[2]))
+    pix = np.zeros(4, dtype=f)
+    if t0 < t1:
+        step = f(dt)                                           # finestLevelCellWidth = 1
+        i0 = int(np.ceil(f(f(t0 - f(step * off)) / step)))
+        t_i = f(f(off + f(i0)) * step)
+        while f(t_i - step) >= t0:
+            t_i = f(t_i - step)
+        while t_i < t0:
+            t_i = f(t_i + step)
+        t_last = t0
+        while True:
+            t_next = min(t_i, t1)
+            ts = f(f(0.5) * f(t_next + t_last))
+            Dt = f(t_next - t_last)
+            t_last = t_next
+            p = (o + ts * d).astype(f)
+            q = (p - f(0.5)).astype(np.float64)                # cell-centre coordinates
+            il = np.maximum(-1, np.floor(q).astype(int))
+            fr = q - il
+            sw = swv = 0.0
+            for dz in (0, 1):
+                for dy in (0, 1):
+                    for dx in (0, 1):
+                        c = il + (dx, dy, dz)
+                        if (c < 0).any() or (c >= n).any():
+                            continue
+                        w = (fr[0] if dx else 1 - fr[0]) * (fr[1] if dy else 1 - fr[1]) * (fr[2] if dz else 1 - fr[2])
+                        sw += w
+                        swv += w * float(vol[c[2], c[1], c[0]])
+            if sw > 1e-20 and Dt != 0:
+                v = swv / sw
+                s = 127.0 * (v - dom[0]) / ((dom[1] - dom[0]) + 1e-20)
+                u = min(127.0, max(0.0, s + 0.5)) / 127.0
+                x = u * 128.0 - 0.5
+                i = int(np.floor(x))
+                a = np.round((x - i) * 256.0) / 256.0          # 8 fractional bits (ties are measure zero here)
+                T0, T1 = xf[min(127, max(0, i))].astype(np.float64), xf[min(127, max(0, i + 1))].astype(np.float64)
+                smp = (1 - a) * T0 + a * T1
+                alpha = 1.0 - (1.0 - smp[3] * opacity_scale) ** float(Dt)
+                k = (1.0 - float(pix[3])) * alpha
+                pix = (pix.astype(np.float64) + k * np.array([smp[0], smp[1], smp[2], 1.0])).astype(f)
+            if pix[3] >= f(0.98) or t_next >= t1:
+                break
+            t_i = f(t_i + step)
+        if pix[3] >= f(0.98):
+            pix = np.array([pix[0] * pix[3], pix[1] * pix[3], pix[2] * pix[3], 1.0], dtype=f)
+    return (pix[3] * pix[:3]).astype(f)                        # composite over a black background (:1701)
+
+
+def test_march_of_a_single_region_scene_follows_the_per_pixel_spec():
+    """the oracle's whole per-pixel pipeline against an independent numpy restatement of SURVEY.md Appendix A on the
+    8^3 brick of ex2 (one region): same pixels within float rounding of the differently ordered arithmetic"""
+    sc = scenes.example("ex2")
+    W, H = 40, 28
+    case = Case(sc, W=W, H=H, grad=0, xf_domains=[(0.0, 1.0)])
+    rgba, acc, st = case.run_oracle(nthreads=2)
+    lo, hi = sc.bounds()
+    cam = harness.default_camera(lo, hi, W, H)
+    xf = harness.default_xf()
+    vol = sc.fields[0].reshape(8, 8, 8)
+    rng = np.random.default_rng(3)
+    worst, lit = 0.0, 0
+    for px, py in zip(rng.integers(0, W, 120), rng.integers(0, H, 120)):
+        want = _pixel_from_spec(sc, vol, cam, xf, (0.0, 1.0), W, H, int(px), int(py))
+        got = acc[py, px, :3]
+        worst = max(worst, float(np.abs(want - got).max()))
+        lit += int(got.sum() > 0)
+    assert lit > 40 and worst < 2e-5, (lit, worst)
