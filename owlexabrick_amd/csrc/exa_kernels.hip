@@ -33,6 +33,9 @@
 #ifndef EXA_OPT_DTPOW2
 #define EXA_OPT_DTPOW2 1
 #endif
+#ifndef EXA_PREPASS_WAVES
+#define EXA_PREPASS_WAVES 4    // waves per SIMD the surfaces pre-pass is compiled for: 2/3/4/5/6 -> 20.2/15.1/12.6/12.6/16.9 ms on C5
+#endif
 #ifndef EXA_OPT_MED3
 #define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
 #endif
@@ -1462,7 +1465,7 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
 // fused kernel would run the march at half its occupancy.
 // ------------------------------------------------------------------------
 template <int STATS>
-__global__ __launch_bounds__(kKdBlock, 3) void surfacePrepassKdKernel(const RenderArgs a)
+__global__ __launch_bounds__(kKdBlock, EXA_PREPASS_WAVES) void surfacePrepassKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
