@@ -102,6 +102,60 @@ def spawn_ranks(n):
     return rc if rc >= 0 else 1
 
 
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "SQ_INSTS_VALU"))     # HBM reads alone (MI355X_MICROARCH.md: separate passes)
+
+
+def live_pmc(child_args, kernel_re, seconds=240.0):
+    """HBM bytes and VALU wave-instructions per launch of the march kernel, measured in THIS run: for each counter group
+    a child `rocprofv3 --pmc ... -- python3 bench.py <same workload> --steps 2` (counters only, no trace domains; the
+    parent is idle meanwhile).  Returns ({counter: mean per dispatch of the shipped kernel}, n_dispatches) or
+    (None, reason).  Counter values are summed over the instances of a dispatch (XCDs / channels)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out_dir = tempfile.mkdtemp(prefix="exa_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", EXA_BENCH_CPU_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "EXA_BENCH_FORCE_DIST", "EXA_BENCH_SHARD"):
+        env.pop(k, None)
+    vals, n_disp = {}, 0
+    try:
+        for i, counters in enumerate(PMC_PASSES):
+            cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(out_dir, f"pass{i}"), "--",
+                   sys.executable, os.path.abspath(__file__), *child_args]
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                                 start_new_session=True)
+            try:
+                _, err = p.communicate(timeout=seconds)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)                     # the process group this call created
+                p.wait()
+                return None, f"pass {i} ({' '.join(counters)}) exceeded {seconds:.0f}s"
+            if p.returncode != 0:
+                tail = (err or b"").decode(errors="replace").strip().splitlines()[-1:] or [""]
+                return None, f"pass {i} ({' '.join(counters)}) exited with {p.returncode}: {tail[0][:200]}"
+            per = {}
+            for f in glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if re.search(kernel_re, row["Kernel_Name"]):
+                        key = (row["Dispatch_Id"], row["Counter_Name"])
+                        per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            for c in counters:
+                v = [x for (d, n), x in per.items() if n == c]
+                if not v:
+                    return None, f"pass {i}: no dispatch of the march kernel carries {c}"
+                vals[c], n_disp = sum(v) / len(v), len(v)
+        return vals, n_disp
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +168,11 @@ def main():
     ap.add_argument("--no-grad", action="store_true", help="gradient shading off (reference default is on)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=45.0)
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"],
+                    help="on: rank 0 of a 1-GPU run measures HBM bytes and VALU instructions of the march kernel live (two "
+                         "short child runs of this script under rocprofv3 --pmc); auto: the same when the full report is "
+                         "being produced (CPU baseline not switched off) and this process is not itself being profiled; "
+                         "off / failure: the committed profiles/hbm_traffic.json of the same workload")
     ap.add_argument("--tile-order", type=int, default=int(os.environ.get("EXA_TILE_ORDER", "4")))
     ap.add_argument("--accel", type=int, default=int(os.environ.get("EXA_ACCEL", "1")),
                     help="1 = region kd-tree walked front to back (default), 0 = LBVH restarted per segment")
@@ -436,26 +495,47 @@ def main():
         }
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         key = f"{args.config}@{args.scale}@{W}"
-        if os.path.exists(traffic_file) and world == 1 and args.iso is None and args.spp == 1:
+        traffic = vi = None
+        plain = world == 1 and not rehearse and not use_dist and args.iso is None and args.spp == 1
+        profiled = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+        if plain and (args.pmc == "on" or (args.pmc == "auto" and want_cpu and not profiled)):
+            # live counters of this very workload: 2 * FETCH_SIZE + WRITE_SIZE (KiB; MI355X_MICROARCH.md: gfx950 counts
+            # a 128-B read request as 64 B) and SQ_INSTS_VALU, per launch of the shipped march kernel
+            child = ["--config", args.config, "--scale", str(args.scale), "--size", str(W), "--steps", "2", "--warmup", "1",
+                     "--tile-order", str(args.tile_order), "--accel", str(args.accel), "--cpu-baseline", "off", "--pmc", "off"]
+            child += ["--no-grad"] if args.no_grad else []
+            for kv in args.option:
+                child += ["--option", kv]
+            t = time.perf_counter()
+            vals, n = live_pmc(child, r"renderFrame(Kd)?Kernel<.*, 0(, (true|false))?>")
+            if vals:
+                traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+                vi = vals["SQ_INSTS_VALU"]
+                out["roofline"]["pmc_source"] = (f"live: rocprofv3 --pmc passes {[' '.join(c) for c in PMC_PASSES]} run by this bench.py "
+                                                 f"on the same workload ({n} launches averaged, {time.perf_counter() - t:.0f}s); "
+                                                 f"traffic = 2*FETCH_SIZE({vals['FETCH_SIZE']:.6g} KiB) + WRITE_SIZE({vals['WRITE_SIZE']:.6g} KiB)")
+            else:
+                log(f"live PMC pass not available ({n}); using {traffic_file}")
+                out["roofline"]["pmc_live_error"] = str(n)
+        if traffic is None and os.path.exists(traffic_file) and world == 1 and args.iso is None and args.spp == 1:
             try:
                 tf = json.load(open(traffic_file))
-                traffic = tf.get(key)
-                out["roofline"]["traffic"] = traffic
+                traffic, vi = tf.get(key), tf.get(key + ":valu_wave_instructions")
                 out["roofline"]["pmc_source"] = tf.get(key + ":note")
-                if traffic:
-                    gbs = traffic / (k_ms * 1e-3) / 1e9
-                    out["roofline"]["hbm_measured"] = {"achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                                       "requested_over_fetched": B / traffic}
-                vi = tf.get(key + ":valu_wave_instructions")
-                if vi:
-                    # what bounds the kernel: vector-instruction issue.  A wave64 VALU instruction holds a SIMD
-                    # for 2 cycles (MI355X_MICROARCH.md, wave scheduling); 256 CUs x 4 SIMDs at 2.4 GHz
-                    floor_ms = vi * 2.0 / (256 * 4) / 2.4e9 * 1e3
-                    out["roofline"]["valu_issue"] = {"wave_instructions": vi, "floor_ms": floor_ms, "frac": floor_ms / k_ms,
-                                                     "peak": "1024 SIMDs x 1 wave64 VALU instruction / 2 cycles at 2.4 GHz",
-                                                     "source": "SQ_INSTS_VALU of the same command under rocprofv3 --pmc (profiles/)"}
             except Exception as e:  # noqa: BLE001
                 log(f"could not read {traffic_file}: {e}")
+        out["roofline"]["traffic"] = traffic
+        if traffic:
+            gbs = traffic / (k_ms * 1e-3) / 1e9
+            out["roofline"]["hbm_measured"] = {"achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                               "requested_over_fetched": B / traffic}
+        if vi:
+            # what bounds the kernel: vector-instruction issue.  A wave64 VALU instruction holds a SIMD
+            # for 2 cycles (MI355X_MICROARCH.md, wave scheduling); 256 CUs x 4 SIMDs at 2.4 GHz
+            floor_ms = vi * 2.0 / (256 * 4) / 2.4e9 * 1e3
+            out["roofline"]["valu_issue"] = {"wave_instructions": vi, "floor_ms": floor_ms, "frac": floor_ms / k_ms,
+                                             "peak": "1024 SIMDs x 1 wave64 VALU instruction / 2 cycles at 2.4 GHz",
+                                             "source": "SQ_INSTS_VALU, see pmc_source"}
         if "valu_issue" not in out["roofline"]:
             out["roofline"]["bound"] = "hbm"       # no counter file for this configuration: only the formula view
         if args.dump:
