@@ -165,6 +165,9 @@ def main():
                     help="root-grid scale of the exajet-like scene (1.0 = ~6.4e8 cells)")
     ap.add_argument("--size", type=int, default=2048)
     ap.add_argument("--config", default="c4_exajet")
+    ap.add_argument("--camera", default="default", choices=["default", "closeup"],
+                    help="default: the viewer's 3/4 view from outside (viewer.cpp:1289-1294); closeup: inside the refined zone")
+    ap.add_argument("--fields", type=int, default=None, help="number of scalar fields = DVR channels (default: the configuration's)")
     ap.add_argument("--no-grad", action="store_true", help="gradient shading off (reference default is on)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=45.0)
@@ -248,7 +251,7 @@ def main():
 
     # ---------------- scene: generate, prepare, upload ----------------
     t0 = time.time()
-    scene = scenes.config(args.config, scale=args.scale, threads=host_threads)
+    scene = scenes.config(args.config, scale=args.scale, threads=host_threads, fields=args.fields)
     t_gen = time.time() - t0
     log(f"scene {args.config} scale {args.scale}: {scene.num_cells:.4g} cells, {scene.bricks7.shape[0]} bricks, "
         f"levels {scene.meta['levels_hist']} ({t_gen:.1f}s)")
@@ -256,7 +259,8 @@ def main():
     # the CPU baseline needs the oracle's own scene (its own region build, serial C);
     # start it now on one core so it overlaps the GPU part
     oracle_box = {}
-    want_cpu = args.cpu_baseline == "auto" and rank == 0 and world == 1 and args.iso is None and args.spp == 1
+    want_cpu = (args.cpu_baseline == "auto" and rank == 0 and world == 1 and args.iso is None and args.spp == 1
+                and len(scene.fields) == 1)
 
     def build_oracle():
         from oracle import pyoracle as po          # bench.py's cpu_baseline leg may use the oracle
@@ -272,7 +276,7 @@ def main():
     prep = binding.Prep(scene, num_threads=host_threads)
     t_prep = time.time() - t0
     lo, hi = prep.voxel_bounds()
-    cam = harness.default_camera(lo, hi, W, H)                 # exa/viewer.cpp:1289-1294
+    cam = (harness.closeup_camera if args.camera == "closeup" else harness.default_camera)(lo, hi, W, H)   # exa/viewer.cpp:1289-1294
     xf = harness.default_xf()
     # EXA_BENCH_SHARD="r,w" (with EXA_BENCH_FORCE_DIST=1 on a one-GPU box): this single rank renders what rank r of a
     # w-GPU job renders and sends its shard through the process group — a rehearsal of one rank's per-frame work
@@ -470,7 +474,9 @@ def main():
             "msamples_per_s": samples_total / 1e6 * fps * args.spp,
             "config": {"workload": f"{args.config} (seed {cfg['seed']:#x} procedural AMR, scale {args.scale}): "
                                    f"{scene.num_cells} cells / {scene.bricks7.shape[0]} bricks / "
-                                   f"{int(prep.scene.numRegions)} regions, {W}x{H} DVR, dt 0.5, alpha ramp, "
+                                   f"{int(prep.scene.numRegions)} regions, {W}x{H} DVR"
+                                   f"{' of %d channels' % len(scene.fields) if len(scene.fields) > 1 else ''}, "
+                                   f"{'camera inside the refined zone, ' if args.camera == 'closeup' else ''}dt 0.5, alpha ramp, "
                                    f"gradient shading {'off' if args.no_grad else 'on'}, space skipping on, frameID 0",
                        "frames_in_flight": (f"{F}: frame k on renderer handle k % {F} (own scene copy, accumulation buffer and stream), "
                                             f"frame k+{F} waits for frame k; every frame is rendered completely and gathered; "
@@ -497,6 +503,7 @@ def main():
         key = f"{args.config}@{args.scale}@{W}"
         traffic = vi = None
         plain = world == 1 and not rehearse and not use_dist and args.iso is None and args.spp == 1
+        stock = args.camera == "default" and args.fields is None        # what profiles/hbm_traffic.json was measured on
         profiled = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
         if plain and (args.pmc == "on" or (args.pmc == "auto" and want_cpu and not profiled)):
             # live counters of this very workload: 2 * FETCH_SIZE + WRITE_SIZE (KiB; MI355X_MICROARCH.md: gfx950 counts
@@ -504,6 +511,7 @@ def main():
             child = ["--config", args.config, "--scale", str(args.scale), "--size", str(W), "--steps", "2", "--warmup", "1",
                      "--tile-order", str(args.tile_order), "--accel", str(args.accel), "--cpu-baseline", "off", "--pmc", "off"]
             child += ["--no-grad"] if args.no_grad else []
+            child += ["--camera", args.camera] + (["--fields", str(args.fields)] if args.fields is not None else [])
             for kv in args.option:
                 child += ["--option", kv]
             t = time.perf_counter()
@@ -517,7 +525,7 @@ def main():
             else:
                 log(f"live PMC pass not available ({n}); using {traffic_file}")
                 out["roofline"]["pmc_live_error"] = str(n)
-        if traffic is None and os.path.exists(traffic_file) and world == 1 and args.iso is None and args.spp == 1:
+        if traffic is None and os.path.exists(traffic_file) and world == 1 and args.iso is None and args.spp == 1 and stock:
             try:
                 tf = json.load(open(traffic_file))
                 traffic, vi = tf.get(key), tf.get(key + ":valu_wave_instructions")

@@ -54,6 +54,18 @@ def default_camera(bounds_lo, bounds_hi, W, H, fovy=70.0):
     return camera(origin, center, [0, 1, 0], fovy, W, H)
 
 
+def closeup_camera(bounds_lo, bounds_hi, W, H, fovy=70.0):
+    """SURVEY 8(d)'s second camera: inside the volume, ahead of and beside the feature at the centre, looking back
+    across it along the long axis — every ray starts inside the grid and most cross the refined zone lengthways
+    (most regions per ray).  (For the exajet-like scene: off the nose, looking over the wing into the wake.)"""
+    lo, hi = np.asarray(bounds_lo, dtype=f32), np.asarray(bounds_hi, dtype=f32)
+    center = (f32(0.5) * (lo + hi)).astype(f32)
+    span = (hi - lo).astype(f32)
+    origin = (center + np.array([-.14, .10, .16], dtype=f32) * span).astype(f32)
+    at = (center + np.array([.15, .0, .0], dtype=f32) * span).astype(f32)
+    return camera(origin, at, [0, 1, 0], fovy, W, H)
+
+
 def default_xf(n=128):
     """exa/viewer.cpp:557-565: alpha ramp i/(n-1).  RGB stands in for the embedded
     cool-warm colormap PNG (exa/ColorMapper is a UI asset, out of scope): an

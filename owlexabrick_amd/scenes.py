@@ -296,9 +296,12 @@ def generated(kind="exajet", seed=1, root=(8, 4, 4), B=8, levels=4, band=1.0, fi
     return sc
 
 
-def config(name, scale=1.0, threads=0, fill=True):
-    """one of CONFIGS; scale < 1 shrinks the root grid (tests), keeping the feature."""
+def config(name, scale=1.0, threads=0, fill=True, fields=None):
+    """one of CONFIGS; scale < 1 shrinks the root grid (tests), keeping the feature; `fields` overrides the number
+    of scalar fields (C4 with 3 channels as a second data point)."""
     c = dict(CONFIGS[name])
+    if fields is not None:
+        c["fields"] = int(fields)
     root = tuple(max(1, int(round(r * scale))) for r in c.pop("root"))
     kind = c.pop("kind")
     return generated(kind=kind, root=root, threads=threads, fill=fill, name=name, **c)
