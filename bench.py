@@ -102,7 +102,27 @@ def spawn_ranks(n):
     return rc if rc >= 0 else 1
 
 
+MARCH_KERNEL_RE = r"renderFrame(Kd)?Kernel<.*, 0(, (true|false))?>"     # the shipped march: STATS template argument 0
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "SQ_INSTS_VALU"))     # HBM reads alone (MI355X_MICROARCH.md: separate passes)
+
+
+def pmc_means(csv_files, kernel_re):
+    """rocprofv3 counter_collection CSVs -> ({counter: mean over the dispatches of the kernels matching kernel_re}, number
+    of dispatches).  A dispatch's value is the sum of its rows (one row per counter instance: XCD, channel, ...)."""
+    import csv
+    import re
+    per = {}
+    for f in csv_files:
+        with open(f, newline="") as fh:
+            for row in csv.DictReader(fh):
+                if re.search(kernel_re, row["Kernel_Name"]):
+                    key = (f, row["Dispatch_Id"], row["Counter_Name"])
+                    per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+    by_counter = {}
+    for (_, _, name), v in per.items():
+        by_counter.setdefault(name, []).append(v)
+    n = max((len(v) for v in by_counter.values()), default=0)
+    return {k: sum(v) / len(v) for k, v in by_counter.items()}, n
 
 
 def live_pmc(child_args, kernel_re, seconds=240.0):
@@ -110,9 +130,7 @@ def live_pmc(child_args, kernel_re, seconds=240.0):
     a child `rocprofv3 --pmc ... -- python3 bench.py <same workload> --steps 2` (counters only, no trace domains; the
     parent is idle meanwhile).  Returns ({counter: mean per dispatch of the shipped kernel}, n_dispatches) or
     (None, reason).  Counter values are summed over the instances of a dispatch (XCDs / channels)."""
-    import csv
     import glob
-    import re
     import shutil
     import signal
     import subprocess
@@ -140,17 +158,12 @@ def live_pmc(child_args, kernel_re, seconds=240.0):
             if p.returncode != 0:
                 tail = (err or b"").decode(errors="replace").strip().splitlines()[-1:] or [""]
                 return None, f"pass {i} ({' '.join(counters)}) exited with {p.returncode}: {tail[0][:200]}"
-            per = {}
-            for f in glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f)):
-                    if re.search(kernel_re, row["Kernel_Name"]):
-                        key = (row["Dispatch_Id"], row["Counter_Name"])
-                        per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
+            means, n_disp = pmc_means(glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True),
+                                      kernel_re)
             for c in counters:
-                v = [x for (d, n), x in per.items() if n == c]
-                if not v:
+                if c not in means:
                     return None, f"pass {i}: no dispatch of the march kernel carries {c}"
-                vals[c], n_disp = sum(v) / len(v), len(v)
+                vals[c] = means[c]
         return vals, n_disp
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
@@ -515,7 +528,7 @@ def main():
             for kv in args.option:
                 child += ["--option", kv]
             t = time.perf_counter()
-            vals, n = live_pmc(child, r"renderFrame(Kd)?Kernel<.*, 0(, (true|false))?>")
+            vals, n = live_pmc(child, MARCH_KERNEL_RE)
             if vals:
                 traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
                 vi = vals["SQ_INSTS_VALU"]
