@@ -33,6 +33,9 @@
 #ifndef EXA_OPT_DTPOW2
 #define EXA_OPT_DTPOW2 1
 #endif
+#ifndef EXA_MARCH_WAVES
+#define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup)
+#endif
 #ifndef EXA_PREPASS_WAVES
 #define EXA_PREPASS_WAVES 4    // waves per SIMD the surfaces pre-pass is compiled for: 2/3/4/5/6 -> 20.2/15.1/12.6/12.6/16.9 ms on C5
 #endif
@@ -1571,7 +1574,7 @@ __global__ __launch_bounds__(kKdBlock, EXA_PREPASS_WAVES) void surfacePrepassKdK
 }
 
 template <bool GRAD, bool FAST, bool MULTI, bool SURF, int STATS, bool SMALL>
-__global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : 6)) void renderFrameKdKernel(const RenderArgs a)
+__global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : EXA_MARCH_WAVES)) void renderFrameKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -2240,7 +2243,10 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
 hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
-  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
+#ifndef EXA_LDS_PAD
+#define EXA_LDS_PAD 0          // occupancy probe: extra bytes of LDS per workgroup (26 KB = 6, 28 KB = 5, 34 KB = 4 workgroups per CU)
+#endif
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12 + EXA_LDS_PAD;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   const bool multi = a.p.numPrimaryChannels > 1;
   // the instrumented variants keep the general address arithmetic (fewer instantiations)
