@@ -216,3 +216,19 @@ def test_c5_exajet_full_4096_dvr_iso_ao_16_frames(exajet_full):
     cfg.R.updateIsoValues([0.5, 0], [0, 0], [1, 0])
     one = cfg.render_frames(1)
     assert np.abs(plain[1] - one[1]).max() > 5e-3
+
+
+def test_field_beyond_4_gib_takes_the_64_bit_offsets():
+    """maximum sizes: one scalar field larger than 4 GiB (exajet-like at scale 1.25: 1.2e9 cells, 4.8 GB per field).
+    32-bit byte offsets and the wave-uniform-base loads are not valid here (exa_module: addr32 = 0), so the shipped
+    march runs its general form with 64-bit addresses on real > 4 GiB offsets.  Same properties as the other
+    configurations, and the WHOLE 512x512 frame against the oracle (every visible brick, wherever its cells lie)"""
+    size = 512
+    cfg = Config("c4_exajet", size, scale=1.25)
+    try:
+        assert cfg.sc.num_cells * 4 > 2 ** 32 and cfg.sc.num_cells < 2 ** 31
+        base = _properties(cfg)
+        win = (0, 0, size, size)
+        _check_crop(base[1], cfg.oracle_frames(win), win, 1, 0, "C4 x1.25, whole frame")
+    finally:
+        cfg.close()
