@@ -66,12 +66,15 @@ struct DeviceScene {
 #ifndef EXA_KD_STACK
 #define EXA_KD_STACK 4      // per-lane short stack of the kd walk (LDS, 12 B per entry) ...
 #endif
+#ifndef EXA_KD_STACK_MULTI
+#define EXA_KD_STACK_MULTI 3   // the multi-channel march: one entry fewer, so that two TF tables + stack + queue fit 6 workgroups per CU
+#endif
 #ifndef EXA_SEG_QUEUE
 #define EXA_SEG_QUEUE 4     // ... and per-lane queue of accepted segments (12 B per entry): 96 B per lane = 6 workgroups per CU.
                             // Measured on C4 (stack/queue), bursts that end when no lane is dry: 4/4 22.42 ms, 3/5 22.56,
                             // 5/3 22.89, 2/6 23.41 (with bursts run until every queue is full: 4/4 24.62, 3/5 24.25)
 #endif
-enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kSegQueue = EXA_SEG_QUEUE,
+enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kKdStackMulti = EXA_KD_STACK_MULTI, kSegQueue = EXA_SEG_QUEUE,
        kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
        kWideSegCap = 256 };   // wide march: leaves a window walker lists per round (16 B each; a fuller window takes more rounds)
 

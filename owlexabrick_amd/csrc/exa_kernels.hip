@@ -36,6 +36,9 @@
 #ifndef EXA_MARCH_WAVES
 #define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup)
 #endif
+#ifndef EXA_MULTI_WAVES
+#define EXA_MULTI_WAVES 6      // ... and the multi-channel march (80 VGPRs; two TF tables + a 3-entry stack: 25 KB of LDS per workgroup)
+#endif
 #ifndef EXA_PREPASS_WAVES
 #define EXA_PREPASS_WAVES 4    // waves per SIMD the surfaces pre-pass is compiled for: 2/3/4/5/6 -> 20.2/15.1/12.6/12.6/16.9 ms on C5
 #endif
@@ -1209,13 +1212,13 @@ struct KdWalk {
 };
 #define EXA_KD_DONE (EXA_KD_EMPTY + 1)
 
-template <int STATS>
+template <int STATS, int KS = kKdStack>
 __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, float *stackF)
 {
   const int count = w.pk.get(PK_SCOUNT);
   if (count > 0) {
     int head = w.pk.get(PK_SHEAD);
-    head = head == 0 ? kKdStack - 1 : head - 1;
+    head = head == 0 ? KS - 1 : head - 1;
     w.pk.set(PK_SHEAD, head);
     w.pk.set(PK_SCOUNT, count - 1);
     w.ref = C.stack[head * kKdBlock];
@@ -1240,7 +1243,8 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, 
 // one step of the walk: pop / descend one level / accept-or-skip a leaf
 // ISOWALK: the iso march multiplies ray.tmax by dt_scale before every trace (exabrick.cu:1434), so the
 // walk is not clamped at the root; the current tmax clamps t1 at the leaf and ends the walk.
-template <bool ISOWALK, int STATS, bool SMALL = false>
+// KS: entries of the lane's short stack (the multi-channel march runs with one fewer, see renderFrameKdKernel)
+template <bool ISOWALK, int STATS, bool SMALL = false, int KS = kKdStack>
 __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a,
                                        float *stackF, int *qRegion, float *qT, const Ray &ray, const int which,
                                        float &walkTmax, const float dtScale, const KdNodeDev *nodes, const int root)
@@ -1282,14 +1286,14 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     }
     w.ref = EXA_KD_EMPTY;
   }
-  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop(C, w, root, stackF);
+  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop<STATS, KS>(C, w, root, stackF);
   // With EXA_OPT_POP1 this is the only pop: a node that leaves nothing to descend into marks the subtree EMPTY and
   // the pop happens here at the start of the lane's next call, in front of that call's node stage — the same
   // sequence of subtrees, with one inlined copy of the pop instead of five for the wave's divergent lanes to run
 #if EXA_OPT_POP1
 #define EXA_KD_POP_LATER() (w.ref = EXA_KD_EMPTY)
 #else
-#define EXA_KD_POP_LATER() kdPop(C, w, root, stackF)
+#define EXA_KD_POP_LATER() kdPop<STATS, KS>(C, w, root, stackF)
 #endif
   // the popped subtree gets its own look at tmin / tmax in the next call
   if (w.ref < 0 || !(w.tf > walkTmin) || (ISOWALK && !(w.tn < walkTmax))) return;
@@ -1329,8 +1333,8 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
       C.stack[head * kKdBlock] = farRef;
       stackF[(2 * head) * kKdBlock] = ts;
       stackF[(2 * head + 1) * kKdBlock] = w.tf;
-      w.pk.set(PK_SHEAD, head == kKdStack - 1 ? 0 : head + 1);
-      if (count == kKdStack) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count + 1);
+      w.pk.set(PK_SHEAD, head == KS - 1 ? 0 : head + 1);
+      if (count == KS) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count + 1);
     }
     w.ref = nearRef;
     w.tf = ts;
@@ -1573,16 +1577,22 @@ __global__ __launch_bounds__(kKdBlock, EXA_PREPASS_WAVES) void surfacePrepassKdK
   }
 }
 
-template <bool GRAD, bool FAST, bool MULTI, bool SURF, int STATS, bool SMALL>
-__global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : EXA_MARCH_WAVES)) void renderFrameKdKernel(const RenderArgs a)
+// MULTI: 0 = one primary channel; 1 = several, at most two TF tables in LDS (the 6-workgroup layout below); 2 = several, more tables
+template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL>
+__global__ __launch_bounds__(kKdBlock, (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 5 : EXA_MARCH_WAVES))) void renderFrameKdKernel(const RenderArgs a)
 {
+  // Entries of the lane's short stack.  The two-table multi-channel march runs with one fewer: a workgroup then needs
+  // 25 KB instead of 28 KB of LDS and a sixth workgroup fits a CU (C3: 30.8 -> 29.4 ms; a shorter stack alone costs ~1 %:
+  // a dropped entry is re-found by a restart from the root).  With three tables the sixth workgroup does not fit either
+  // way and the 80-VGPR build only costs (3 channels on C4: +2 %): MULTI == 2 keeps 4 entries and 5 waves per SIMD.
+  constexpr int KS = MULTI == 1 ? kKdStackMulti : kKdStack;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
-  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
-  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
-  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(KS) * kKdBlock * 4) + threadIdx.x;
+  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(KS) * kKdBlock * 12) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(sp0 + size_t(KS) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
@@ -1694,7 +1704,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI ? 5 : EXA_MARCH_WAVES)) void rende
         C.lap(ST_T_WALK);
         do {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
-          if (want) kdStep<false, STATS, SMALL>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
+          if (want) kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
       }
       if (!haveSeg) {
@@ -2246,22 +2256,22 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
 #ifndef EXA_LDS_PAD
 #define EXA_LDS_PAD 0          // occupancy probe: extra bytes of LDS per workgroup (26 KB = 6, 28 KB = 5, 34 KB = 4 workgroups per CU)
 #endif
-  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12 + EXA_LDS_PAD;
+  // 0: one primary channel; 1: several with at most two TF tables (3-entry stack, 6 workgroups per CU); 2: several, more tables.
+  // The instrumented variants exist for 0 and 2 only.
+  const int mode = a.p.numPrimaryChannels > 1 ? ((a.numXfChannels <= 2 && !stats) ? 1 : 2) : 0;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4)
+                   + size_t((mode == 1 ? kKdStackMulti : kKdStack) + kSegQueue) * kKdBlock * 12 + EXA_LDS_PAD;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
-  const bool multi = a.p.numPrimaryChannels > 1;
   // the instrumented variants keep the general address arithmetic (fewer instantiations)
   const bool small = a.mul24 && a.addr32;
 #define EXA_LAUNCH(G, F, M, I, S, A) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S, A>), grid, block, lds, s, a)
-#define EXA_PICK2(G, F, M, I) do { if (stats == 1) EXA_LAUNCH(G, F, M, I, 1, false); else if (stats == 2) EXA_LAUNCH(G, F, M, I, 2, false); \
+#define EXA_PICK2(G, F, M, I) do { if (stats == 1) EXA_LAUNCH(G, F, (M ? 2 : 0), I, 1, false); else if (stats == 2) EXA_LAUNCH(G, F, (M ? 2 : 0), I, 2, false); \
                                    else if (small) EXA_LAUNCH(G, F, M, I, 0, true); else EXA_LAUNCH(G, F, M, I, 0, false); } while (0)
 #define EXA_PICK(G, F, M) do { if (surf) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
-  if (grad) {
-    if (fast) { if (multi) EXA_PICK(true, true, true); else EXA_PICK(true, true, false); }
-    else      { if (multi) EXA_PICK(true, false, true); else EXA_PICK(true, false, false); }
-  } else {
-    if (fast) { if (multi) EXA_PICK(false, true, true); else EXA_PICK(false, true, false); }
-    else      { if (multi) EXA_PICK(false, false, true); else EXA_PICK(false, false, false); }
-  }
+#define EXA_PICKM(G, F) do { if (mode == 0) EXA_PICK(G, F, 0); else if (mode == 1) EXA_PICK(G, F, 1); else EXA_PICK(G, F, 2); } while (0)
+  if (grad) { if (fast) EXA_PICKM(true, true); else EXA_PICKM(true, false); }
+  else      { if (fast) EXA_PICKM(false, true); else EXA_PICKM(false, false); }
+#undef EXA_PICKM
 #undef EXA_PICK
 #undef EXA_PICK2
 #undef EXA_LAUNCH

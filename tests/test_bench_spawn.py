@@ -55,8 +55,8 @@ def test_pmc_means_sums_instances_and_averages_dispatches_of_the_shipped_kernel(
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     MARCH_RE = bench.MARCH_KERNEL_RE
-    shipped = "void exa::renderFrameKdKernel<true, true, false, false, 0, true>(exa::RenderArgs)"
-    counted = "void exa::renderFrameKdKernel<true, true, false, false, 1, false>(exa::RenderArgs)"
+    shipped = "void exa::renderFrameKdKernel<true, true, 0, false, 0, true>(exa::RenderArgs)"
+    counted = "void exa::renderFrameKdKernel<true, true, 0, false, 1, false>(exa::RenderArgs)"
     rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value"]
     rows += [f'1,1,0,"{counted}",FETCH_SIZE,1000.0']
     rows += [f'2,2,0,"{shipped}",FETCH_SIZE,10.0', f'2,2,0,"{shipped}",FETCH_SIZE,30.0']       # two instances
