@@ -94,6 +94,20 @@ struct Lcg {
 // FAST (fast_math=1): 1-ulp hardware reciprocal / square root in the per-sample epilogue instead of the
 // correctly rounded expansions (~10 instructions each); the walk and the sample positions stay exact
 template <bool FAST> __device__ __forceinline__ float fdiv(float a, float b) { return FAST ? a * __builtin_amdgcn_rcpf(b) : a / b; }
+// The quotients that decide WHICH transfer-function texels a sample blends and with which 1/256 weight (the cell value
+// sumWV/sumW and the two divisions of the TF coordinate) get one correction step on top of the fast form: q = a*y with
+// y = rcp(b) is within ~1.5 ulp, the remainder r = a - q*b is exact in an fma, and q + r*y rounds to the correctly
+// rounded quotient except at near-ties (none in 2e7 random trials; the plain fast form is off by an ulp in 2 of 3).
+// An ulp there is not harmless: the filter weight is quantised, so it can move a sample's opacity by a whole step
+// |T[i+1].a - T[i].a| / 256 (seeded random TF tables: accumulation differences of 2e-3).  q is clamped to the finite
+// range first, so that an overflowing quotient still saturates the TF coordinate instead of turning into inf - inf.
+template <bool FAST> __device__ __forceinline__ float fdivExact(float a, float b, float y /* rcp(b), FAST only */)
+{
+  if (!FAST) return a / b;
+  const float q = __builtin_amdgcn_fmed3f(a * y, -3.402823466e+38f, 3.402823466e+38f);
+  return __builtin_fmaf(__builtin_fmaf(-q, b, a), y, q);
+}
+template <bool FAST> __device__ __forceinline__ float fdivExact(float a, float b) { return fdivExact<FAST>(a, b, FAST ? __builtin_amdgcn_rcpf(b) : 0.f); }
 template <bool FAST> __device__ __forceinline__ float fsqrt(float a) { return FAST ? __builtin_amdgcn_sqrtf(a) : sqrtf(a); }
 
 struct Ray { V3 org, dir; float tmin, tmax; };
@@ -174,10 +188,15 @@ __device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameSt
 {
   // HAVE_RCP (fast_math only): rcpRange is the caller's copy of rcp((hi - lo) + 1e-20f), the value fdiv<true> computes here
   const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
-  float scalar = (FAST && HAVE_RCP) ? ((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo)) * rcpRange
-                                    : fdiv<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
+  float scalar = (FAST && HAVE_RCP) ? fdivExact<true>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f, rcpRange)
+                                    : fdivExact<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
   scalar = fminf(EXA_NUM_XF_VALUES - 1.f, fmaxf(0.f, scalar + .5f));
-  scalar = fdiv<FAST>(scalar, EXA_NUM_XF_VALUES - 1.f);
+  if (FAST) {        // scalar in [0, 127]: no clamp needed; 1/127 as a constant
+    const float q = scalar * (1.f / (EXA_NUM_XF_VALUES - 1.f));
+    scalar = __builtin_fmaf(__builtin_fmaf(-q, EXA_NUM_XF_VALUES - 1.f, scalar), 1.f / (EXA_NUM_XF_VALUES - 1.f), q);
+  } else {
+    scalar = scalar / (EXA_NUM_XF_VALUES - 1.f);
+  }
   const float x = scalar * float(EXA_NUM_XF_VALUES) - 0.5f;
   const float fl = floorf(x);
   const float al = ((x - fl) + fracMagic) - fracMagic;
@@ -1772,7 +1791,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 
       C.phase(ST_W_FINAL);
       if (B.sumW > 1e-20f) {
         C.count(ST_SAMPLES);
-        const float cellValue = fdiv<FAST>(B.sumWV, B.sumW);
+        const float cellValue = fdivExact<FAST>(B.sumWV, B.sumW);
         V3 grad = mk(0.f, 0.f, 0.f);
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
@@ -2149,7 +2168,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       Color4 smp; smp.x = smp.y = smp.z = smp.w = 0.f;
       int contributes = 0;
       if (mine && B.sumW > 1e-20f && actual_dt != 0.f) {
-        const float cellValue = fdiv<FAST>(B.sumWV, B.sumW);
+        const float cellValue = fdivExact<FAST>(B.sumWV, B.sumW);
         V3 grad = mk(0.f, 0.f, 0.f);
         if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                             B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,

@@ -1,0 +1,79 @@
+"""Seeded random parity cases: scene (block size, levels, feature, one or two fields), frame size, camera (outside,
+inside, axis-aligned — rays parallel to the split planes), transfer function (ramp / band / random table / steps),
+step size, opacity scale, gradient shading, iso-surfaces, clip box, space skipping, frame id.  `random_case(seed)` is a
+pure function of the seed; tests/test_gpu_fuzz.py runs a fixed set under `-m gpu`, `python tests/gpu_fuzz.py A B` sweeps
+any range of seeds on a GPU box."""
+import numpy as np
+
+from common import Case, band_xf
+from owlexabrick_amd import harness, scenes
+
+
+def _random_xf(rng, kind):
+    xf = harness.default_xf()
+    n = xf.shape[0]
+    t = np.arange(n) / (n - 1.0)
+    if kind == "band":
+        lo = float(rng.uniform(0.05, 0.6))
+        return band_xf(lo, lo + float(rng.uniform(0.1, 0.35)))
+    if kind == "table":                                   # rough random table: every texel pair has a different slope
+        xf[:, 3] = rng.uniform(0.0, 1.0, n).astype(np.float32) * (rng.uniform(0, 1, n) > 0.3)
+        xf[:, :3] = rng.uniform(0.0, 1.0, (n, 3)).astype(np.float32)
+    elif kind == "steps":                                 # piecewise constant with exact zeros (space skipping edges)
+        k = int(rng.integers(3, 9))
+        levels = rng.choice([0.0, 0.0, 0.15, 0.5, 1.0], size=k)
+        xf[:, 3] = levels[np.minimum((t * k).astype(int), k - 1)].astype(np.float32)
+    elif kind == "faint":
+        xf[:, 3] = (0.02 * t).astype(np.float32)
+    return xf
+
+
+def random_case(seed):
+    rng = np.random.default_rng(0xE7A000 + seed)
+    B = int(rng.choice([2, 4, 4, 8]))
+    levels = int(rng.integers(1, 4))
+    root = tuple(int(v) for v in rng.integers(1, 4, 3))
+    if B == 8:
+        root = tuple(min(r, 2) for r in root)
+    fields = int(rng.choice([1, 1, 1, 2]))
+    feature = str(rng.choice(["shell", "plume"]))
+    scene = scenes.amr(seed=int(rng.integers(1, 1 << 20)), root=root, B=B, levels=levels, feature=feature, fields=fields)
+    ext = np.array(root, dtype=np.float64) * B * (1 << (levels - 1))
+    W, H = int(rng.integers(17, 97)), int(rng.integers(9, 81))
+    mode = str(rng.choice(["default", "outside", "inside", "axis", "grazing"]))
+    fovy = float(rng.uniform(25.0, 95.0))
+    centre = 0.5 * ext
+    if mode == "default":
+        camera = None
+    elif mode == "outside":
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        camera = (list(centre + d * float(rng.uniform(0.9, 2.5)) * ext.max()), list(centre + rng.uniform(-0.2, 0.2, 3) * ext), [0, 1, 0], fovy)
+    elif mode == "inside":
+        camera = (list(rng.uniform(0.15, 0.85, 3) * ext), list(rng.uniform(0.0, 1.0, 3) * ext), [0, 1, 0], fovy)
+    elif mode == "axis":                                   # centre ray exactly along an axis: zero direction components
+        ax = int(rng.integers(0, 3)); sgn = float(rng.choice([-1.0, 1.0]))
+        o = centre.copy(); o[ax] += sgn * 1.4 * ext[ax]
+        o[(ax + 1) % 3] = float(np.round(o[(ax + 1) % 3]))  # on a cell face of the finest level
+        at = o.copy(); at[ax] = centre[ax]
+        camera = (list(o), list(at), [0, 0, 1] if ax == 1 else [0, 1, 0], fovy)
+    else:                                                  # grazing: along a face of the volume
+        o = np.array([-0.3 * ext[0], ext[1] * float(rng.choice([0.0, 1.0])), 0.5 * ext[2]])
+        camera = (list(o), [ext[0], o[1], 0.5 * ext[2]], [0, 1, 0], fovy)
+    xf_kind = str(rng.choice(["ramp", "band", "table", "steps", "faint"]))
+    xfs = [_random_xf(rng, xf_kind) for _ in range(fields)]
+    iso = None
+    if rng.uniform() < 0.35:
+        iso = [(float(rng.uniform(0.15, 0.85)), int(rng.integers(0, fields)))]
+        if rng.uniform() < 0.3:
+            iso.append((float(rng.uniform(0.15, 0.85)), int(rng.integers(0, fields))))
+    clip = None
+    if rng.uniform() < 0.2:
+        lo = rng.uniform(0.0, 0.4, 3) * ext
+        clip = (list(lo), list(lo + rng.uniform(0.3, 0.6, 3) * ext))
+    kw = dict(W=W, H=H, grad=int(rng.integers(0, 2)), iso=iso, xf=xfs, dt=float(rng.choice([0.5, 0.5, 0.25, 1.0, 0.37, 2.0])),
+              opacity_scale=float(rng.choice([1.0, 1.0, 0.3, 0.05])), space_skipping=int(rng.uniform() < 0.8), clip=clip,
+              frameID=int(rng.choice([0, 0, 3])), camera=camera, grad_iso=int(rng.integers(0, 2)),
+              multi=bool(fields == 1 or rng.uniform() < 0.7), xf_domains=[(0.0, 1.0)] * fields if rng.uniform() < 0.5 else None)
+    desc = dict(seed=seed, B=B, levels=levels, root=root, fields=fields, feature=feature, camera=mode, xf=xf_kind,
+                **{k: v for k, v in kw.items() if k not in ("xf", "camera", "xf_domains")})
+    return Case(scene, **kw), desc

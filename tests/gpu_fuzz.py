@@ -1,0 +1,61 @@
+"""Sweep of seeded random parity cases on a GPU box (not collected by pytest):
+    python tests/gpu_fuzz.py FIRST LAST [--keep-going]
+For each seed: the oracle against the HIP module through the C ABI, both walks (kd, LBVH), library powf
+(`fast_math = 0`): accumulation buffer within the tolerance of tests/common.py, RGBA8 within 1 LSB, identical work
+counters, no slab-test mismatch; and the shipped kernel (counting off, `fast_math` 0 and 1 defaults) equal to the counting
+variant bit for bit / within the flip tolerance."""
+import sys
+import time
+
+import numpy as np
+
+from common import compare
+from fuzz_cases import random_case
+
+STAT_KEYS = ["segments", "sample_evals", "samples", "brick_visits", "corner_loads", "iso_segments", "iso_evals"]
+
+
+def check(seed):
+    """list of failure strings (empty = pass)"""
+    bad = []
+    case, desc = random_case(seed)
+    case.fast_math = 0
+    o = case.run_oracle()
+    for accel in (1, 0):
+        case.accel = accel
+        h = case.run_hip(stats=True)
+        r = compare(o, h)
+        if r["accum_bad"] or r["rgba_bad"]:
+            bad.append(f"accel {accel}: {r}")
+        if {k: o[2][k] for k in STAT_KEYS} != {k: h[2][k] for k in STAT_KEYS}:
+            bad.append(f"accel {accel}: counters {[(k, o[2][k], h[2][k]) for k in STAT_KEYS if o[2][k] != h[2][k]]}")
+        if h[2]["diag"][8] != 0:
+            bad.append(f"accel {accel}: {h[2]['diag'][8]} slab-test mismatches")
+        plain = case.run_hip()
+        if not (np.array_equal(plain[1].view(np.uint32), h[1].view(np.uint32)) and np.array_equal(plain[0], h[0])):
+            bad.append(f"accel {accel}: shipped kernel differs from the counting variant")
+    case.accel, case.fast_math = 1, None          # the defaults a caller gets
+    h = case.run_hip(stats=True)
+    r = compare(o, h)
+    if not (r["flips_ok"] and r["rgba_bad"] <= 3 * r["flip_pixels"]):
+        bad.append(f"defaults: {r}")
+    return bad, desc
+
+
+if __name__ == "__main__":
+    first, last = int(sys.argv[1]), int(sys.argv[2])
+    keep = "--keep-going" in sys.argv
+    fails, t0 = 0, time.time()
+    for seed in range(first, last + 1):
+        bad, desc = check(seed)
+        if bad:
+            fails += 1
+            print(f"FAIL seed {seed}: {desc}", flush=True)
+            for b in bad:
+                print("    ", b, flush=True)
+            if not keep:
+                break
+        elif seed % 10 == 0:
+            print(f"seed {seed} ok ({time.time() - t0:.0f}s)", flush=True)
+    print(f"{last - first + 1 - fails if keep or not fails else '?'} passed, {fails} failed, {time.time() - t0:.0f}s", flush=True)
+    sys.exit(1 if fails else 0)
