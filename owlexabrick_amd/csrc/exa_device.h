@@ -99,6 +99,7 @@ struct RenderArgs {
   uint32_t           leafBeginBits, leafSizeBits;
   const RegionRec   *regionRec;
   int32_t            kdRoot;
+  int32_t            kdIsoRoot;     // where the iso walk starts: kdRoot, or EXA_KD_EMPTY + 1 (= done) when the tree is one inactive leaf
   float              kdLo[3], kdHi[3];   // box of the kd root = union of all brick domains
   const BvhNode     *meshNodes;     // BVH over the triangle surfaces (NULL: none)
   const float       *meshVerts;     // 3 floats per vertex, world space

@@ -1394,7 +1394,7 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
     w.tn = fmaxf(r0, walkTmin);
     w.tf = r1;
     w.tEnd = r1;
-    w.ref = (hit && w.tn < w.tf) ? a.kdRoot : EXA_KD_DONE;
+    w.ref = (hit && w.tn < w.tf) ? a.kdIsoRoot : EXA_KD_DONE;
   }
   for (int seg = 0;; seg++) {
     if (seg >= (1 << 22)) { C.guardTripped = true; break; }
@@ -1404,7 +1404,7 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
       for (int g = 0;; g++) {
         if (g >= (1 << 24)) { C.guardTripped = true; w.ref = EXA_KD_DONE; break; }
         const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;
-        if (want) kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale, a.kdNodes, a.kdRoot);
+        if (want) kdStep<true>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 1, walkTmax, dt_scale, a.kdNodes, a.kdIsoRoot);
         if (!anyLane(w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) break;     // no lane is dry any more
       }
     }

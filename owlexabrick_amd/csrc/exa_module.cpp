@@ -227,6 +227,7 @@ struct ExaHipRenderer {
   DevBuf<int32_t> kdLevelIds;
   std::vector<int> kdLevelBegin;
   int32_t kdRoot = EXA_KD_EMPTY;
+  bool rootLeafVolActive = true, rootLeafIsoActive = true;   // activity of the only region when the kd tree is one leaf
   bool haveKd = false;
   int accel = 1;                     // 1 = kd walk when available, 0 = LBVH
   float kdLo[3], kdHi[3];
@@ -625,6 +626,13 @@ struct ExaHipRenderer {
       HIP_TRY(this, hipEventRecord(ev1, s));
       HIP_TRY(this, hipEventSynchronize(ev1));
       HIP_TRY(this, hipEventElapsedTime(&last.rebuild_ms, ev2, ev1));
+      if (haveKd && kdRoot < 0 && kdRoot != EXA_KD_EMPTY) {        // the kd tree is a single leaf: its activity lives here
+        uint8_t f[2] = {1, 1};
+        HIP_TRY(this, hipMemcpy(&f[0], volActive.p + ~kdRoot, 1, hipMemcpyDeviceToHost));
+        if (needIso) HIP_TRY(this, hipMemcpy(&f[1], isoActive.p + ~kdRoot, 1, hipMemcpyDeviceToHost));
+        rootLeafVolActive = f[0] != 0;
+        rootLeafIsoActive = f[1] != 0;
+      }
     }
     return 0;
   }
@@ -722,10 +730,14 @@ struct ExaHipRenderer {
     const bool packed = kdMarchNodes.p != nullptr && !(stats && statsMode == 1);
     a.kdMarchNodes = packed ? kdMarchNodes.p : kdNodes.p;
     a.kdMarchRoot = packed ? kdMarchRoot : kdRoot;
+    // A tree that is one leaf (a one-region scene) has no node to carry the activity bits: the walks start at
+    // "done" when that region is inactive (the reference's BVHs hold no primitive then)
+    if (!rootLeafVolActive) a.kdMarchRoot = EXA_KD_EMPTY + 1;
     a.leafBeginBits = packed ? leafBeginBits : 0;
     a.leafSizeBits = packed ? leafSizeBits : 0;
     a.regionRec = regionRec.p;
     a.kdRoot = kdRoot;
+    a.kdIsoRoot = rootLeafIsoActive ? kdRoot : EXA_KD_EMPTY + 1;
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
     worldBounds(a.worldLo, a.worldHi);
     a.meshNodes = meshNodes.p; a.meshVerts = meshVerts.p; a.meshTris = meshTris.p; a.numTris = numTris;

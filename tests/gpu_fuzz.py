@@ -25,9 +25,17 @@ def check(seed):
         case.accel = accel
         h = case.run_hip(stats=True)
         r = compare(o, h)
-        if r["accum_bad"] or r["rgba_bad"]:
+        # a ray whose opacity crosses 0.98 within an ulp of powf may stop one sample earlier or later on one side
+        # (tests/common.py: FLIP_BOUND, FLIP_FRACTION; 2 of 2000 seeds have such a pixel): then the pixel is bounded
+        # by the flip tolerance and the counters by a few samples, otherwise everything is exact
+        flipped = r["flip_pixels"] > 0 and r["flips_ok"] and r["rgba_bad"] == 0
+        if (r["accum_bad"] or r["rgba_bad"]) and not flipped:
             bad.append(f"accel {accel}: {r}")
-        if {k: o[2][k] for k in STAT_KEYS} != {k: h[2][k] for k in STAT_KEYS}:
+        if flipped:
+            slack = {k: 16 * r["flip_pixels"] * (8 if k == "corner_loads" else 1) for k in STAT_KEYS}
+            if any(abs(o[2][k] - h[2][k]) > slack[k] for k in STAT_KEYS):
+                bad.append(f"accel {accel}: counters beyond a flipped pixel {[(k, o[2][k], h[2][k]) for k in STAT_KEYS if o[2][k] != h[2][k]]}")
+        elif {k: o[2][k] for k in STAT_KEYS} != {k: h[2][k] for k in STAT_KEYS}:
             bad.append(f"accel {accel}: counters {[(k, o[2][k], h[2][k]) for k in STAT_KEYS if o[2][k] != h[2][k]]}")
         if h[2]["diag"][8] != 0:
             bad.append(f"accel {accel}: {h[2]['diag'][8]} slab-test mismatches")

@@ -460,3 +460,24 @@ def test_full_frame_properties_at_benchmark_size():
     bad = (d > ACCUM_ATOL + 1e-4 * np.abs(o[1]).max()).any(axis=-1).sum()
     assert bad <= 5 and d.max() <= 0.021          # only termination flips, see tests/common.py
     assert o[2]["samples"] > 0
+
+
+@pytest.mark.parametrize("accel", [1, 0], ids=["kd", "lbvh"])
+def test_one_region_scene_skips_its_region_when_inactive(accel):
+    """a scene of one region: the kd tree is a single leaf and no node carries the activity bits.  The region must still
+    be skipped when the TF is transparent over its value range (no segment, as in the reference, whose volume BVH then
+    holds no primitive) and the iso walk when no iso value lies in its range (found by the seeded random cases)"""
+    sc = scenes.example("c1_64")                          # values in [0, 1]
+    xf = harness.default_xf()
+    xf[:, 3] = (np.arange(128) >= 120).astype(np.float32)  # opaque only above 0.94
+    for kw, expect_seg in ((dict(xf=xf, xf_domains=[(0.0, 4.0)]), 0),            # the field maps to texels 0..32: transparent
+                           (dict(xf=xf, xf_domains=[(0.0, 4.0)], space_skipping=0), None),
+                           (dict(iso=[(2.5, 0)]), None)):                           # iso value outside the field's range
+        case = Case(sc, W=64, H=48, accel=accel, fast_math=0, **kw)
+        o, h = case.run_oracle(), case.run_hip(stats=True)
+        assert compare(o, h)["accum_bad"] == 0
+        assert {k: o[2][k] for k in STAT_KEYS} == {k: h[2][k] for k in STAT_KEYS}, kw
+        if expect_seg is not None:
+            assert h[2]["segments"] == expect_seg
+        if "iso" in kw:
+            assert h[2]["iso_segments"] == 0 and o[2]["iso_segments"] == 0
