@@ -77,3 +77,78 @@ def random_case(seed):
     desc = dict(seed=seed, B=B, levels=levels, root=root, fields=fields, feature=feature, camera=mode, xf=xf_kind,
                 **{k: v for k, v in kw.items() if k not in ("xf", "camera", "xf_domains")})
     return Case(scene, **kw), desc
+
+
+def _octahedron(centre, r):
+    v = [np.asarray(centre) + r * np.array(d, dtype=np.float64) for d in ([1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1])]
+    t = [[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]
+    return np.array(v), np.array(t)
+
+
+def random_rich_case(seed):
+    """the second family: the same knobs plus the surface features and the other scene generator — AO rays, contour
+    planes, triangle meshes, a voxel-space transform with a world-space camera, the C++ scene generator's three kinds,
+    several accumulated frames, the full-precision TF filter.  Returns (case, desc, frames)."""
+    rng = np.random.default_rng(0x51C4000 + seed)
+    fields = int(rng.choice([1, 1, 2]))
+    if rng.uniform() < 0.3:
+        kind = str(rng.choice(["lanl", "gear", "exajet"]))
+        B = int(rng.choice([4, 8]))
+        levels = int(rng.integers(2, 4))
+        root = (int(rng.integers(1, 4)), int(rng.integers(1, 3)), int(rng.integers(1, 3)))
+        scene = scenes.generated(kind=kind, seed=int(rng.integers(1, 1 << 20)), root=root, B=B, levels=levels, fields=fields)
+        what = kind
+    else:
+        B = int(rng.choice([2, 4, 4]))
+        levels = int(rng.integers(1, 4))
+        root = tuple(int(v) for v in rng.integers(1, 4, 3))
+        what = str(rng.choice(["shell", "plume"]))
+        scene = scenes.amr(seed=int(rng.integers(1, 1 << 20)), root=root, B=B, levels=levels, feature=what, fields=fields)
+    ext = np.array(root, dtype=np.float64) * B * (1 << (levels - 1))
+    centre = 0.5 * ext
+    W, H = int(rng.integers(24, 129)), int(rng.integers(16, 97))
+    fovy = float(rng.uniform(30.0, 90.0))
+    xfm = None
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    if rng.uniform() < 0.2:
+        # voxel = vx*wx + vy*wy + vz*wz + p: the world is the unit cube moved by -p/ext; the camera is given in world space
+        p = rng.uniform(-3.0, 3.0, 3)
+        xfm = dict(vx=[float(ext[0]), 0, 0], vy=[0, float(ext[1]), 0], vz=[0, 0, float(ext[2])], p=[float(v) for v in p])
+        wc = 0.5 - p / ext
+        camera = (list(wc + d * float(rng.uniform(1.2, 2.5))), list(wc + rng.uniform(-0.1, 0.1, 3)), [0, 1, 0], fovy)
+    elif rng.uniform() < 0.3:
+        camera = (list(rng.uniform(0.15, 0.85, 3) * ext), list(rng.uniform(0.0, 1.0, 3) * ext), [0, 1, 0], fovy)
+    else:
+        camera = (list(centre + d * float(rng.uniform(0.9, 2.2)) * ext.max()), list(centre + rng.uniform(-0.2, 0.2, 3) * ext), [0, 1, 0], fovy)
+    xf_kind = str(rng.choice(["ramp", "band", "table", "steps", "faint"]))
+    xfs = [_random_xf(rng, xf_kind) for _ in range(fields)]
+    iso = None
+    if rng.uniform() < 0.5:
+        iso = [(float(rng.uniform(0.15, 0.85)), int(rng.integers(0, fields)))]
+        if rng.uniform() < 0.3:
+            iso.append((float(rng.uniform(0.15, 0.85)), int(rng.integers(0, fields))))
+    contour = None
+    if rng.uniform() < 0.25:
+        contour = []
+        for _ in range(int(rng.integers(1, 4))):
+            n = rng.normal(size=3)
+            contour.append(([float(v) for v in n], float(rng.uniform(0.2, 0.8)), int(rng.integers(0, fields))))
+    meshes = None
+    if rng.uniform() < 0.2 and xfm is None:
+        meshes = [_octahedron(centre + rng.uniform(-0.15, 0.15, 3) * ext, float(rng.uniform(0.1, 0.3)) * float(ext.min()))]
+        if rng.uniform() < 0.5:
+            z = float(rng.uniform(0.2, 0.8) * ext[2])
+            q = np.array([[0.1 * ext[0], 0.1 * ext[1], z], [0.9 * ext[0], 0.1 * ext[1], z], [0.9 * ext[0], 0.9 * ext[1], z], [0.1 * ext[0], 0.9 * ext[1], z]])
+            meshes.append((q, np.array([[0, 1, 2], [0, 2, 3]])))
+    ao = int((iso is not None or meshes is not None) and rng.uniform() < 0.4)
+    ao_length = float(rng.choice([1e20, 0.3])) * (1.0 if xfm is not None else float(ext.max())) if ao else 1e20
+    frames = int(rng.choice([1, 1, 2, 3]))
+    kw = dict(W=W, H=H, grad=int(rng.integers(0, 2)), iso=iso, xf=xfs, dt=float(rng.choice([0.5, 0.5, 0.25, 1.0, 0.37])),
+              opacity_scale=float(rng.choice([1.0, 0.3, 0.05])), space_skipping=int(rng.uniform() < 0.8),
+              frameID=0, camera=camera, xfm=xfm, grad_iso=int(rng.integers(0, 2)),
+              multi=bool(fields == 1 or rng.uniform() < 0.7), xf_domains=[(0.0, 1.0)] * fields,
+              contour=contour, meshes=meshes, ao=ao, ao_length=ao_length, tf_filter=(0 if rng.uniform() < 0.15 else None))
+    desc = dict(seed=seed, scene=what, B=B, levels=levels, root=root, fields=fields, xf=xf_kind, frames=frames,
+                xfm=xfm is not None, contour=len(contour or []), meshes=len(meshes or []),
+                **{k: v for k, v in kw.items() if k not in ("xf", "camera", "xf_domains", "xfm", "contour", "meshes")})
+    return Case(scene, **kw), desc, frames

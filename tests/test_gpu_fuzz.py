@@ -10,3 +10,10 @@ pytestmark = pytest.mark.gpu
 def test_random_case_matches_oracle(seed):
     bad, desc = check(seed)
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_rich_case_matches_oracle(seed):
+    """the second family: AO, contour planes, meshes, voxel-space transform, generated scenes, accumulated frames"""
+    bad, desc = check(seed, rich=True)
+    assert not bad, (desc, bad)
