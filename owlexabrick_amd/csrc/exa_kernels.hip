@@ -1303,7 +1303,12 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
       walkTmin = t1 * (1.0000001f);                          // exabrick.cu:1698 / :1457
       if (ISOWALK) walkTmax = walkTmax * dtScale;            // the next trace's tmax (:1434)
     }
-    w.ref = EXA_KD_EMPTY;
+    // A region that the trace's tmax cut short is not finished: the reference's intersection program reports the
+    // CLAMPED exit (boxTest clamps to the ray's tmax, exabrick.cu:354-369), so the next trace starts just behind it and,
+    // its tmax being dt_scale times larger (:1434), finds the rest of the same region.  Only a finite tmax with
+    // dt_scale > 1 gets here (AO rays of finite length under a magnifying voxel-space transform); the leaf stays current
+    // until a trace reaches its far face or finds nothing (dt_scale <= 1: t0 >= t1 next time).
+    if (!(ISOWALK && hit && t1 < w.tf)) w.ref = EXA_KD_EMPTY;
   }
   if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop<STATS, KS>(C, w, root, stackF);
   // With EXA_OPT_POP1 this is the only pop: a node that leaves nothing to descend into marks the subtree EMPTY and
