@@ -28,8 +28,39 @@ def _random_xf(rng, kind):
     return xf
 
 
-def random_case(seed):
-    rng = np.random.default_rng(0xE7A000 + seed)
+def _random_grids(rng):
+    """a random partition of a box into bricks of any shape and level (the reference's `.grids` form, one brick per grid:
+    tools/artificial): extents are multiples of 4 finest cells, a brick of level l has extent / 2^l cells per axis (so
+    1-cell-thin and 127-free odd shapes occur), neighbours may differ by two levels, a brick is sometimes left out (a hole
+    in the domain), values are trilinear between random corner values or constant."""
+    ext = [int(rng.choice([8, 12, 16, 24])) for _ in range(3)]
+    boxes = [((0, 0, 0), tuple(ext))]
+    for _ in range(int(rng.integers(1, 10))):
+        i = int(rng.integers(0, len(boxes)))
+        lo, hi = boxes[i]
+        ax = int(rng.integers(0, 3))
+        n4 = (hi[ax] - lo[ax]) // 4
+        if n4 < 2:
+            continue
+        cut = lo[ax] + 4 * int(rng.integers(1, n4))
+        a_hi = list(hi); a_hi[ax] = cut
+        b_lo = list(lo); b_lo[ax] = cut
+        boxes[i] = (lo, tuple(a_hi))
+        boxes.append((tuple(b_lo), hi))
+    grids = []
+    for lo, hi in boxes:
+        if len(boxes) > 2 and rng.uniform() < 0.1:
+            continue
+        lvl = int(rng.integers(0, 3))
+        dims = [(hi[k] - lo[k]) >> lvl for k in range(3)]
+        vals = [float(rng.uniform(0, 1))] * 8 if rng.uniform() < 0.25 else [float(v) for v in rng.uniform(0, 1, 8)]
+        grids.append([lo[0], lo[1], lo[2], dims[0], dims[1], dims[2], lvl] + vals)
+    return grids, np.array(ext, dtype=np.float64)
+
+
+def random_case(seed, grids=False):
+    """grids=True: the third family — the same knobs on a random partition into bricks of any shape and level"""
+    rng = np.random.default_rng((0x6E1D5000 if grids else 0xE7A000) + seed)
     B = int(rng.choice([2, 4, 4, 8]))
     levels = int(rng.integers(1, 4))
     root = tuple(int(v) for v in rng.integers(1, 4, 3))
@@ -37,8 +68,13 @@ def random_case(seed):
         root = tuple(min(r, 2) for r in root)
     fields = int(rng.choice([1, 1, 1, 2]))
     feature = str(rng.choice(["shell", "plume"]))
-    scene = scenes.amr(seed=int(rng.integers(1, 1 << 20)), root=root, B=B, levels=levels, feature=feature, fields=fields)
-    ext = np.array(root, dtype=np.float64) * B * (1 << (levels - 1))
+    if grids:
+        g, ext = _random_grids(rng)
+        scene = scenes.artificial(g, name=f"grids{seed}")
+        fields, feature, root, B, levels = 1, "grids", tuple(int(e) for e in ext), 0, len(g)
+    else:
+        scene = scenes.amr(seed=int(rng.integers(1, 1 << 20)), root=root, B=B, levels=levels, feature=feature, fields=fields)
+        ext = np.array(root, dtype=np.float64) * B * (1 << (levels - 1))
     W, H = int(rng.integers(17, 97)), int(rng.integers(9, 81))
     mode = str(rng.choice(["default", "outside", "inside", "axis", "grazing"]))
     fovy = float(rng.uniform(25.0, 95.0))

@@ -1,5 +1,5 @@
 """Sweep of seeded random parity cases on a GPU box (not collected by pytest):
-    python tests/gpu_fuzz.py FIRST LAST [--rich] [--keep-going]
+    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids] [--keep-going]
 For each seed: the oracle against the HIP module through the C ABI, both walks (kd, LBVH), library powf
 (`fast_math = 0`): accumulation buffer within the tolerance of tests/common.py, RGBA8 within 1 LSB, identical work
 counters, no slab-test mismatch; and the shipped kernel (counting off, `fast_math` 0 and 1 defaults) equal to the counting
@@ -20,10 +20,10 @@ def check(seed, rich=False):
     """list of failure strings (empty = pass)"""
     bad = []
     frames = 1
-    if rich:
+    if rich is True:
         case, desc, frames = random_rich_case(seed)
     else:
-        case, desc = random_case(seed)
+        case, desc = random_case(seed, grids=(rich == "grids"))
     case.fast_math = 0
     o = case.run_oracle(frames=frames)
     for accel in (1, 0):
@@ -71,7 +71,7 @@ def check(seed, rich=False):
 if __name__ == "__main__":
     first, last = int(sys.argv[1]), int(sys.argv[2])
     keep = "--keep-going" in sys.argv
-    rich = "--rich" in sys.argv
+    rich = True if "--rich" in sys.argv else ("grids" if "--grids" in sys.argv else False)
     fails, t0 = 0, time.time()
     for seed in range(first, last + 1):
         bad, desc = check(seed, rich)

@@ -18,3 +18,10 @@ def test_random_rich_case_matches_oracle(seed):
     """the second family: AO, contour planes, meshes, voxel-space transform, generated scenes, accumulated frames"""
     bad, desc = check(seed, rich=True)
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_grids_case_matches_oracle(seed):
+    """the third family: random partitions into bricks of any shape and level, with holes"""
+    bad, desc = check(seed, rich="grids")
+    assert not bad, (desc, bad)
