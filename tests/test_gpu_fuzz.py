@@ -25,3 +25,11 @@ def test_random_grids_case_matches_oracle(seed):
     """the third family: random partitions into bricks of any shape and level, with holes"""
     bad, desc = check(seed, rich="grids")
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_case_is_independent_of_the_launch(seed):
+    """launch order, cost feedback, wide march, shards of a random world + untile, multi-device handle: bit-identical"""
+    from gpu_fuzz_sched import check as check_sched
+    bad, desc = check_sched(seed)
+    assert not bad, (desc, bad)
