@@ -33,3 +33,11 @@ def test_random_case_is_independent_of_the_launch(seed):
     from gpu_fuzz_sched import check as check_sched
     bad, desc = check_sched(seed)
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sequence_of_state_changes_equals_a_fresh_renderer(seed):
+    """six random setter calls on one handle, each followed by frames that equal a fresh renderer's in that state"""
+    from gpu_fuzz_state import check as check_state
+    bad, desc = check_state(seed)
+    assert not bad, (desc, bad)
