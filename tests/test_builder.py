@@ -109,3 +109,12 @@ def test_built_bricks_feed_the_host_prep():
     sc = scenes.Scene(np.array(b7), np.concatenate(ids), [scal])
     P = binding.Prep(sc)
     assert P.scene.totalCells == len(cells) and P.scene.numRegions >= len(b7)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_builder_on_seeded_random_cell_sets(seed):
+    """tests/fuzz_builder.py: random partitions into dense blocks (holes, negative coordinates, duplicates), the three
+    builder types, random --max-leaf-width: bytes equal to the restatement and a valid ExaBricks file"""
+    from fuzz_builder import check
+    bad, desc = check(seed)
+    assert not bad, (desc, bad)
