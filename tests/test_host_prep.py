@@ -133,3 +133,11 @@ def test_exported_kd_tree_reproduces_region_domains(sc):
         stack.append((int(n["left"]), l, hl))
         stack.append((int(n["right"]), lr, h))
     assert (seen == 1).all()
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_prep_on_seeded_random_scenes(seed):
+    """tests/fuzz_prep.py: the scenes of the random case families, exa_prep_* against the oracle byte for byte"""
+    from fuzz_prep import check
+    bad, desc = check(seed)
+    assert not bad, (desc, bad)
