@@ -104,7 +104,9 @@ struct OrScene {
   float     tfFracMagic;   /* 32768: filter fraction held in 1.8 fixed point (CUDA tex1D); 0: full precision */
   float    *meshVerts; int32_t *meshTris; size_t numVerts, numTris;   /* all surfaces, concatenated */
   /* streamline tracer state (OptixRenderer.h:160-170) */
-  int tracerEnabled, tracerChannels[3], numTraces, numTimesteps, timestep;
+  int tracerEnabled, tracerChannels[3], numTraces, numTimesteps;
+  int timestepHost;   /* traces.timestepHost: counts every advanceTracer call */
+  int timestep;       /* traces.currentTimestep, what the device programs read: uploaded only while <= numTimesteps */
   float steplen; float *traces;                                        /* numTraces*numTimesteps*3 */
   float     vb_lo[3], vb_hi[3];
 };
@@ -375,14 +377,16 @@ void or_reset_tracer(OrScene *S, int enabled, const int channels[3], int numTrac
   S->traces = (float *)calloc((size_t)numTraces * numTimesteps * 3 + 1, sizeof(float));
   if (!S->traces) die_oom();
   for (int i = 0; i < numTraces; i++) memcpy(&S->traces[(size_t)i * numTimesteps * 3], &seeds[3 * i], 3 * sizeof(float));
-  S->timestep = 0;
+  S->timestep = S->timestepHost = 0;
 }
-/* OptixRenderer::advanceTracer (:474-487) */
+/* OptixRenderer::advanceTracer (:474-487): the host counter always advances, the device copy (currentTimestep) only while
+ * the counter is <= numTimesteps — further calls leave the picture as it is */
 int or_advance_tracer(OrScene *S)
 {
   if (!S->tracerEnabled) return 0;
-  S->timestep++;
-  return S->timestep <= S->numTimesteps;
+  S->timestepHost++;
+  if (S->timestepHost <= S->numTimesteps) { S->timestep = S->timestepHost; return 1; }
+  return 0;
 }
 const float *or_traces(const OrScene *S) { return S->traces; }
 int or_tracer_timestep(const OrScene *S) { return S->timestep; }

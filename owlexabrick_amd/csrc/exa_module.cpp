@@ -646,6 +646,8 @@ struct ExaHipRenderer {
     if (!haveTracer) return 0;
     const int NT = tracer.numTimesteps;
     const long long nprims = (long long)tracer.numTraces * (NT - 1);
+    // the device copy of the timestep stops at numTimesteps (advanceTracer uploads it only while <= numTimesteps)
+    const int timestep = std::min(this->timestep, NT);
     if (timestep < 2 || nprims <= 0) return 0;
     HIP_TRY(this, hipStreamSynchronize(s));
     std::vector<float> host(traces.n);
@@ -743,7 +745,7 @@ struct ExaHipRenderer {
     a.meshNodes = meshNodes.p; a.meshVerts = meshVerts.p; a.meshTris = meshTris.p; a.numTris = numTris;
     a.streamNodes = streamNodes.p; a.traces = traces.p; a.numStreamPrims = numStreamPrims;
     for (int k = 0; k < 3; k++) a.tracerChannels[k] = tracer.channels[k];
-    a.numTraces = tracer.numTraces; a.numTimesteps = tracer.numTimesteps; a.timestep = timestep; a.steplen = tracer.steplen;
+    a.numTraces = tracer.numTraces; a.numTimesteps = tracer.numTimesteps; a.timestep = std::min(timestep, tracer.numTimesteps); a.steplen = tracer.steplen;
     if (haveTracer && tracer.enabled && timestep < tracer.numTimesteps && timestep >= 1) {
       // computeTraces: the threads with pixelIdx < numTraces (exabrick.cu:1539)
       const long long px = (long long)W * H;

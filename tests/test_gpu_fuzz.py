@@ -41,3 +41,12 @@ def test_random_sequence_of_state_changes_equals_a_fresh_renderer(seed):
     from gpu_fuzz_state import check as check_state
     bad, desc = check_state(seed)
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_tracer_run_matches_oracle(seed):
+    """streamline tracer: random seeds (also outside the grid), timesteps, step length, channel order; one advance more than
+    numTimesteps (the device copy of the timestep stops there, OptixRenderer.cpp:476-487)"""
+    from gpu_fuzz_tracer import check as check_tracer
+    bad, desc = check_tracer(seed)
+    assert not bad, (desc, bad)
