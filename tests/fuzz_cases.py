@@ -58,15 +58,18 @@ def _random_grids(rng):
     return grids, np.array(ext, dtype=np.float64)
 
 
-def random_case(seed, grids=False):
-    """grids=True: the third family — the same knobs on a random partition into bricks of any shape and level"""
-    rng = np.random.default_rng((0x6E1D5000 if grids else 0xE7A000) + seed)
+def random_case(seed, grids=False, many=False):
+    """grids=True: the third family — the same knobs on a random partition into bricks of any shape and level;
+    many=True: three or four scalar fields (the march variant for more than two TF tables)"""
+    rng = np.random.default_rng((0x6E1D5000 if grids else (0x3A4F000 if many else 0xE7A000)) + seed)
     B = int(rng.choice([2, 4, 4, 8]))
     levels = int(rng.integers(1, 4))
     root = tuple(int(v) for v in rng.integers(1, 4, 3))
     if B == 8:
         root = tuple(min(r, 2) for r in root)
     fields = int(rng.choice([1, 1, 1, 2]))
+    if many:
+        fields = int(rng.choice([3, 3, 4]))
     feature = str(rng.choice(["shell", "plume"]))
     if grids:
         g, ext = _random_grids(rng)

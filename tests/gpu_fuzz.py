@@ -1,5 +1,5 @@
 """Sweep of seeded random parity cases on a GPU box (not collected by pytest):
-    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids] [--keep-going]
+    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids | --many] [--keep-going]
 For each seed: the oracle against the HIP module through the C ABI, both walks (kd, LBVH), library powf
 (`fast_math = 0`): accumulation buffer within the tolerance of tests/common.py, RGBA8 within 1 LSB, identical work
 counters, no slab-test mismatch; and the shipped kernel (counting off, `fast_math` 0 and 1 defaults) equal to the counting
@@ -23,7 +23,7 @@ def check(seed, rich=False):
     if rich is True:
         case, desc, frames = random_rich_case(seed)
     else:
-        case, desc = random_case(seed, grids=(rich == "grids"))
+        case, desc = random_case(seed, grids=(rich == "grids"), many=(rich == "many"))
     case.fast_math = 0
     o = case.run_oracle(frames=frames)
     for accel in (1, 0):
@@ -42,7 +42,7 @@ def check(seed, rich=False):
         # a ray whose opacity crosses 0.98 within an ulp of powf may stop one sample earlier or later on one side
         # (tests/common.py: FLIP_BOUND, FLIP_FRACTION; 2 of 2000 seeds have such a pixel): then the pixel is bounded
         # by the flip tolerance and the counters by a few samples, otherwise everything is exact
-        flipped = r["flip_pixels"] > 0 and r["flips_ok"] and r["rgba_bad"] == 0
+        flipped = r["flip_pixels"] > 0 and r["flips_ok"] and r["rgba_bad"] <= 3 * r["flip_pixels"]
         if (r["accum_bad"] or r["rgba_bad"]) and not flipped:
             bad.append(f"accel {accel}: {r}")
         if flipped:
@@ -71,7 +71,7 @@ def check(seed, rich=False):
 if __name__ == "__main__":
     first, last = int(sys.argv[1]), int(sys.argv[2])
     keep = "--keep-going" in sys.argv
-    rich = True if "--rich" in sys.argv else ("grids" if "--grids" in sys.argv else False)
+    rich = True if "--rich" in sys.argv else ("grids" if "--grids" in sys.argv else ("many" if "--many" in sys.argv else False))
     fails, t0 = 0, time.time()
     for seed in range(first, last + 1):
         bad, desc = check(seed, rich)

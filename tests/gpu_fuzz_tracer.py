@@ -51,7 +51,7 @@ def check(seed):
             bad.append(f"traces differ at frame {f}")
             break
         r = compare(o, (h_rgba, h_acc, None))
-        if (r["accum_bad"] or r["rgba_bad"]) and not (r["flip_pixels"] > 0 and r["flips_ok"] and r["rgba_bad"] == 0):
+        if (r["accum_bad"] or r["rgba_bad"]) and not (r["flip_pixels"] > 0 and r["flips_ok"] and r["rgba_bad"] <= 3 * r["flip_pixels"]):
             bad.append(f"frame {f}: {r}")
             break
     R.close()

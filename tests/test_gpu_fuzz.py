@@ -50,3 +50,9 @@ def test_random_tracer_run_matches_oracle(seed):
     from gpu_fuzz_tracer import check as check_tracer
     bad, desc = check_tracer(seed)
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_case_with_three_or_four_fields_matches_oracle(seed):
+    bad, desc = check(seed, rich="many")
+    assert not bad, (desc, bad)
