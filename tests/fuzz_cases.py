@@ -191,3 +191,34 @@ def random_rich_case(seed):
                 xfm=xfm is not None, contour=len(contour or []), meshes=len(meshes or []),
                 **{k: v for k, v in kw.items() if k not in ("xf", "camera", "xf_domains", "xfm", "contour", "meshes")})
     return Case(scene, **kw), desc, frames
+
+
+def random_deep_case(seed):
+    """the seventh family: scenes of the C++ generator with 1e5..2e6 cells and thousands of regions — kd trees deep enough
+    for the 4-entry short stack to overflow and restart, leaf references packed into the march tree, long rays through
+    faint TFs, cameras inside the refined zone."""
+    rng = np.random.default_rng(0xDEE9000 + seed)
+    kind = str(rng.choice(["lanl", "gear", "exajet"]))
+    levels = int(rng.integers(3, 5))
+    root = (int(rng.integers(2, 6)), int(rng.integers(2, 4)), int(rng.integers(2, 4)))
+    fields = int(rng.choice([1, 1, 2]))
+    scene = scenes.generated(kind=kind, seed=int(rng.integers(1, 1 << 20)), root=root, B=8, levels=levels, fields=fields,
+                             band=float(rng.choice([1.0, 2.5])))
+    ext = np.array(root, dtype=np.float64) * 8 * (1 << (levels - 1))
+    centre = 0.5 * ext
+    W, H = int(rng.integers(48, 161)), int(rng.integers(32, 121))
+    fovy = float(rng.uniform(30.0, 90.0))
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    if rng.uniform() < 0.4:
+        camera = (list(rng.uniform(0.2, 0.8, 3) * ext), list(rng.uniform(0.0, 1.0, 3) * ext), [0, 1, 0], fovy)
+    else:
+        camera = (list(centre + d * float(rng.uniform(0.7, 1.8)) * ext.max()), list(centre + rng.uniform(-0.2, 0.2, 3) * ext), [0, 1, 0], fovy)
+    xf_kind = str(rng.choice(["ramp", "band", "table", "steps", "faint", "faint"]))
+    xfs = [_random_xf(rng, xf_kind) for _ in range(fields)]
+    iso = [(float(rng.uniform(0.2, 0.8)), int(rng.integers(0, fields)))] if rng.uniform() < 0.3 else None
+    kw = dict(W=W, H=H, grad=int(rng.integers(0, 2)), iso=iso, xf=xfs, dt=float(rng.choice([0.5, 0.5, 1.0, 0.37])),
+              opacity_scale=float(rng.choice([1.0, 0.3, 0.05])), space_skipping=int(rng.uniform() < 0.85), camera=camera,
+              grad_iso=int(rng.integers(0, 2)), xf_domains=[(0.0, 1.0)] * fields)
+    desc = dict(seed=seed, kind=kind, levels=levels, root=root, fields=fields, xf=xf_kind, cells=int(scene.num_cells),
+                **{k: v for k, v in kw.items() if k not in ("xf", "camera", "xf_domains")})
+    return Case(scene, **kw), desc

@@ -56,3 +56,10 @@ def test_random_tracer_run_matches_oracle(seed):
 def test_random_case_with_three_or_four_fields_matches_oracle(seed):
     bad, desc = check(seed, rich="many")
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_deep_scene_matches_oracle(seed):
+    """generated scenes of 1e5..2e6 cells: deep kd trees (short-stack restarts), packed leaf references, long rays"""
+    bad, desc = check(seed, rich="deep")
+    assert not bad, (desc, bad)
