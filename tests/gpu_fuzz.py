@@ -1,5 +1,5 @@
 """Sweep of seeded random parity cases on a GPU box (not collected by pytest):
-    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids | --many | --deep] [--keep-going]
+    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids | --many | --deep | --domains] [--keep-going]
 For each seed: the oracle against the HIP module through the C ABI, both walks (kd, LBVH), library powf
 (`fast_math = 0`): accumulation buffer within the tolerance of tests/common.py, RGBA8 within 1 LSB, identical work
 counters, no slab-test mismatch; and the shipped kernel (counting off, `fast_math` 0 and 1 defaults) equal to the counting
@@ -25,7 +25,13 @@ def check(seed, rich=False):
     elif rich == "deep":
         case, desc = random_deep_case(seed)
     else:
-        case, desc = random_case(seed, grids=(rich == "grids"), many=(rich == "many"))
+        case, desc = random_case(seed, grids=(rich == "grids"), many=(rich == "many"))     # also "domains"
+    if rich == "domains":
+        # the TF domain per channel: degenerate, reversed, very narrow, far wider than the data, off to one side
+        rng = np.random.default_rng(0xD0A1000 + seed)
+        case.xf_domains = [[(0.0, 0.0), (0.5, 0.5), (1.0, 0.0), (0.4, 0.4001), (-5.0, 5.0), (0.9, 3.0), (-2.0, 0.1), (0.0, 1e-30),
+                            (0.25, 0.75)][int(rng.integers(0, 9))] for _ in case.scene.fields]
+        desc["xf_domains"] = case.xf_domains
     case.fast_math = 0
     o = case.run_oracle(frames=frames)
     for accel in (1, 0):
@@ -77,7 +83,7 @@ def check(seed, rich=False):
 if __name__ == "__main__":
     first, last = int(sys.argv[1]), int(sys.argv[2])
     keep = "--keep-going" in sys.argv
-    rich = True if "--rich" in sys.argv else ("grids" if "--grids" in sys.argv else ("many" if "--many" in sys.argv else ("deep" if "--deep" in sys.argv else False)))
+    rich = True if "--rich" in sys.argv else ("grids" if "--grids" in sys.argv else ("many" if "--many" in sys.argv else ("deep" if "--deep" in sys.argv else ("domains" if "--domains" in sys.argv else False))))
     fails, t0 = 0, time.time()
     for seed in range(first, last + 1):
         bad, desc = check(seed, rich)
