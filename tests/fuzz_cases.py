@@ -55,6 +55,9 @@ def _random_grids(rng):
         dims = [(hi[k] - lo[k]) >> lvl for k in range(3)]
         vals = [float(rng.uniform(0, 1))] * 8 if rng.uniform() < 0.25 else [float(v) for v in rng.uniform(0, 1, 8)]
         grids.append([lo[0], lo[1], lo[2], dims[0], dims[1], dims[2], lvl] + vals)
+    if not grids:                                         # every brick left out (one seed in a few thousand): keep one
+        lo, hi = boxes[0]
+        grids.append([lo[0], lo[1], lo[2], hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2], 0] + [0.25] * 8)
     return grids, np.array(ext, dtype=np.float64)
 
 

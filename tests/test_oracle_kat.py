@@ -444,3 +444,12 @@ def test_march_of_a_single_region_scene_follows_the_per_pixel_spec():
         worst = max(worst, float(np.abs(want - got).max()))
         lit += int(got.sum() > 0)
     assert lit > 40 and worst < 2e-5, (lit, worst)
+
+
+@pytest.mark.parametrize("seed", range(25))
+def test_oracle_against_the_definitions_on_seeded_random_partitions(seed):
+    """tests/fuzz_oracle.py: hat-basis reconstruction, region partition, pruned region search == brute force, on random
+    partitions into bricks of any shape and level with holes (10 000 seeds swept)"""
+    from fuzz_oracle import check
+    bad, desc = check(seed)
+    assert not bad, (desc, bad)
