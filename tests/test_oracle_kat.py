@@ -453,3 +453,12 @@ def test_oracle_against_the_definitions_on_seeded_random_partitions(seed):
     from fuzz_oracle import check
     bad, desc = check(seed)
     assert not bad, (desc, bad)
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_oracle_pixels_follow_the_spec_on_seeded_random_one_brick_scenes(seed):
+    """tests/fuzz_spec.py: the whole per-pixel pipeline against the numpy restatement of SURVEY.md Appendix A with a random
+    brick, camera (also inside / along an axis), smooth TF, domain, step, opacity scale and frame id (3 000 seeds swept)"""
+    from fuzz_spec import check
+    bad, desc = check(seed)
+    assert not bad, desc
