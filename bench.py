@@ -172,7 +172,7 @@ def live_pmc(child_args, kernel_re, seconds=240.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50, help="timed frames (SURVEY 8(d): 3 warm-up + 50 timed, as viewer.cpp:309)")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--scale", type=float, default=float(os.environ.get("EXA_BENCH_SCALE", "1.0")),
                     help="root-grid scale of the exajet-like scene (1.0 = ~6.4e8 cells)")
