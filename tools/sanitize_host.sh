@@ -1,0 +1,58 @@
+#!/bin/bash
+# AddressSanitizer + UndefinedBehaviorSanitizer over the HOST code, driven by the seeded random inputs of tests/fuzz_*.py
+# (no GPU: device ASan is not available on this pool).  Builds into a scratch directory:
+#   exaBuilder (owlexabrick_amd/host/exa_builder.cpp)          <- tests/fuzz_builder.py, 300 cell sets
+#   the oracle (oracle/exa_oracle.c, + float-cast-overflow)    <- tests/fuzz_oracle.py, fuzz_spec.py, whole frames of 3 case families
+#   the module's host preparation (csrc/exa_prep.cpp)          <- tests/fuzz_prep.py, 600 scenes (needs csrc/*.o: run make first)
+# usage: tools/sanitize_host.sh [scratch dir]
+set -eu
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+D=${1:-/tmp/exa_san}
+mkdir -p "$D"
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -O1 -g"
+g++ $SAN -std=c++17 -o "$D/exaBuilder" "$ROOT/owlexabrick_amd/host/exa_builder.cpp" -lpthread
+gcc $SAN -fsanitize=float-cast-overflow -fno-sanitize-recover=float-cast-overflow -std=c11 -fPIC -ffp-contract=off -fno-fast-math -D_GNU_SOURCE \
+    -shared -o "$D/libexa_oracle.so" "$ROOT/oracle/exa_oracle.c" -lm -lpthread
+CS="$ROOT/owlexabrick_amd/csrc"
+/opt/rocm/bin/hipcc $SAN -std=c++17 -fPIC -ffp-contract=off -c "$CS/exa_prep.cpp" -o "$D/exa_prep.o"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$D/libexa_hip.so" \
+    "$CS/exa_kernels.o" "$CS/exa_lbvh.o" "$CS/exa_module.o" "$D/exa_prep.o" -lpthread 2>/dev/null
+GCC_RT="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
+CLANG_RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.asan-x86_64.so" | head -1)
+export ASAN_OPTIONS=detect_leaks=0
+cd "$ROOT/tests"
+python3 - "$D" <<'PY'
+import sys
+D = sys.argv[1]
+sys.path.insert(0, '.')
+import test_builder
+test_builder.EXE = D + "/exaBuilder"
+import fuzz_builder
+fails = sum(bool(fuzz_builder.check(s)[0]) for s in range(300))
+print(f"exaBuilder under ASan+UBSan: {fails} failed of 300")
+sys.exit(1 if fails else 0)
+PY
+LD_PRELOAD="$GCC_RT" python3 - "$D" <<'PY'
+import sys
+D = sys.argv[1]
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
+from oracle import pyoracle
+pyoracle._LIB = D + "/libexa_oracle.so"
+import fuzz_oracle, fuzz_spec
+from fuzz_cases import random_case, random_rich_case
+fails = sum(bool(m.check(s)[0]) for s in range(120) for m in (fuzz_oracle, fuzz_spec))
+for s in range(60):
+    c, d, f = random_rich_case(s); c.run_oracle(frames=f, nthreads=4)
+    random_case(s)[0].run_oracle(nthreads=4)
+    random_case(s, grids=True)[0].run_oracle(nthreads=4)
+print(f"oracle under ASan+UBSan(+float-cast-overflow): {fails} failed of 240 checks, 180 whole frames rendered")
+sys.exit(1 if fails else 0)
+PY
+EXA_HIP_LIB="$D/libexa_hip.so" LD_PRELOAD="$CLANG_RT" python3 - <<'PY'
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
+import fuzz_prep
+fails = sum(bool(fuzz_prep.check(s)[0]) for s in range(600))
+print(f"host preparation (exa_prep.cpp) under ASan+UBSan: {fails} failed of 600")
+sys.exit(1 if fails else 0)
+PY
