@@ -4,6 +4,7 @@
 #   exaBuilder (owlexabrick_amd/host/exa_builder.cpp)          <- tests/fuzz_builder.py, 300 cell sets
 #   the oracle (oracle/exa_oracle.c, + float-cast-overflow)    <- tests/fuzz_oracle.py, fuzz_spec.py, whole frames of 3 case families
 #   the module's host preparation (csrc/exa_prep.cpp)          <- tests/fuzz_prep.py, 600 scenes (needs csrc/*.o: run make first)
+#   the facade's file loaders (host/exa_host.cpp via exaRender --info) <- 150 random scenes written in the reference's formats
 # usage: tools/sanitize_host.sh [scratch dir]
 set -eu
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -54,5 +55,31 @@ sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import fuzz_prep
 fails = sum(bool(fuzz_prep.check(s)[0]) for s in range(600))
 print(f"host preparation (exa_prep.cpp) under ASan+UBSan: {fails} failed of 600")
+sys.exit(1 if fails else 0)
+PY
+/opt/rocm/bin/hipcc $SAN -std=c++17 -shared-libsan -o "$D/exaRender" "$ROOT/owlexabrick_amd/host/exaRender.cpp" "$ROOT/owlexabrick_amd/host/exa_host.cpp" \
+    -L"$ROOT/owlexabrick_amd" -lexa_hip -Wl,-rpath,"$ROOT/owlexabrick_amd" -lpthread 2>/dev/null
+LD_PRELOAD="$CLANG_RT" python3 - "$D" <<'PY'
+import subprocess, sys, tempfile
+import numpy as np
+D = sys.argv[1]
+sys.path.insert(0, '.'); sys.path.insert(0, '..')
+from fuzz_cases import random_case, _octahedron
+from owlexabrick_amd import scenes
+fails = 0
+for seed in range(150):
+    rng = np.random.default_rng(0x10AD000 + seed)
+    sc = random_case(seed, grids=(seed % 3 == 0), many=(seed % 5 == 0))[0].scene
+    with tempfile.TemporaryDirectory() as d:
+        lo, hi = sc.bounds()
+        meshes = [_octahedron(0.5 * (np.asarray(lo) + np.asarray(hi)), 2.0)] if rng.uniform() < 0.4 else None
+        cfg = scenes.write_exa(sc, d, "s", meshes=meshes)
+        with open(cfg, "a") as f:
+            if rng.uniform() < 0.5: f.write('scalar e expr "%0 2 * 1 +"\n')
+            if rng.uniform() < 0.3: f.write('value_range -1 3\n')
+            if rng.uniform() < 0.3: f.write('vector m s_0.scalars s_0.scalars s_0.scalars # c\n')
+        r = subprocess.run([D + "/exaRender", cfg, "--info"], capture_output=True, text=True, timeout=120)
+        fails += int(r.returncode != 0 or "runtime error" in r.stderr or "ERROR: " in r.stderr)
+print(f"file loaders (exa_host.cpp) under ASan+UBSan: {fails} failed of 150")
 sys.exit(1 if fails else 0)
 PY
