@@ -2,7 +2,7 @@
 on seeded random one-brick scenes (CPU only):  python tests/fuzz_spec.py FIRST LAST
 Random brick edge (2..12 cells), corner values, camera (outside / inside / along an axis), smooth random TF (the spec is
 written in float64 around the quantised filter weight, so only TFs whose neighbouring texels differ little can be held to
-2e-5), TF domain, step, opacity scale, frame id (other jitter), frame size; 60 random pixels per case."""
+2e-5), TF domain, step, opacity scale, gradient shading on / off, frame id (other jitter), frame size; 60 random pixels per case."""
 import sys
 import time
 
@@ -48,16 +48,17 @@ def check(seed):
     dt = float(rng.choice([0.5, 0.25, 1.0, 0.37, 2.0]))
     osc = float(rng.choice([1.0, 0.3, 0.05]))
     frame = int(rng.choice([0, 1, 7]))
-    case = Case(sc, W=W, H=H, grad=0, xf=xf, xf_domains=[dom], dt=dt, opacity_scale=osc, frameID=frame, camera=cam)
+    grad = int(rng.integers(0, 2))
+    case = Case(sc, W=W, H=H, grad=grad, xf=xf, xf_domains=[dom], dt=dt, opacity_scale=osc, frameID=frame, camera=cam)
     rgba, acc, st = case.run_oracle(nthreads=2)
     vol = sc.fields[0].reshape(n, n, n)
     worst, at_px = 0.0, None
     for px, py in zip(rng.integers(0, W, 60), rng.integers(0, H, 60)):
-        want = _pixel_from_spec(sc, vol, cam, xf, dom, W, H, int(px), int(py), dt=dt, opacity_scale=osc, frame=frame)
+        want = _pixel_from_spec(sc, vol, cam, xf, dom, W, H, int(px), int(py), dt=dt, opacity_scale=osc, frame=frame, grad=bool(grad))
         d = float(np.abs(want - acc[py, px, :3]).max())
         if d > worst:
             worst, at_px = d, (int(px), int(py))
-    desc = dict(seed=seed, n=n, W=W, H=H, camera=mode, xf=kind, dom=dom, dt=dt, opacity_scale=osc, frame=frame, worst=worst, at=at_px)
+    desc = dict(seed=seed, n=n, W=W, H=H, camera=mode, xf=kind, dom=dom, dt=dt, opacity_scale=osc, frame=frame, grad=grad, worst=worst, at=at_px)
     # the spec computes the TF coordinate in float64, the oracle in float32: a sample next to a 1/256 boundary of the
     # filter weight may round to the other side and then moves by one quantisation step of the table (two per pixel allowed)
     step = float(np.abs(np.diff(xf, axis=0)).max()) * osc / 256.0

@@ -346,7 +346,7 @@ def test_contour_plane_colour_and_shading():
     assert st["segments"] > 0                    # contour planes switch space skipping off: the volume is still walked
 
 
-def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0):
+def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0, grad=False):
     """SURVEY.md Appendix A for a ONE-region, one-brick, level-0 scene without gradient shading, written from the spec
     in numpy float32 — independent of oracle/exa_oracle.c: LCG jitter, pinhole ray, slab test against the region
     domain (bounds +- half a cell), first sample at the first (off+i)*dt >= t0, midpoint sampling with partial first
@@ -396,15 +396,22 @@ def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=
             il = np.maximum(-1, np.floor(q).astype(int))
             fr = q - il
             sw = swv = 0.0
+            sd, sdc = np.zeros(3), np.zeros(3)
             for dz in (0, 1):
                 for dy in (0, 1):
                     for dx in (0, 1):
                         c = il + (dx, dy, dz)
                         if (c < 0).any() or (c >= n).any():
                             continue
-                        w = (fr[0] if dx else 1 - fr[0]) * (fr[1] if dy else 1 - fr[1]) * (fr[2] if dz else 1 - fr[2])
+                        wa = [(fr[0] if dx else 1 - fr[0]), (fr[1] if dy else 1 - fr[1]), (fr[2] if dz else 1 - fr[2])]
+                        w = wa[0] * wa[1] * wa[2]
+                        sval = float(vol[c[2], c[1], c[0]])
                         sw += w
-                        swv += w * float(vol[c[2], c[1], c[0]])
+                        swv += w * sval
+                        for k, hi_side in enumerate((dx, dy, dz)):       # d/dk of the hat: +-1 (unit scale) times the other two
+                            dk = (1.0 if hi_side else -1.0) * wa[(k + 1) % 3] * wa[(k + 2) % 3]
+                            sd[k] += dk * sval
+                            sdc[k] += dk
             if sw > 1e-20 and Dt != 0:
                 v = swv / sw
                 s = 127.0 * (v - dom[0]) / ((dom[1] - dom[0]) + 1e-20)
@@ -414,6 +421,11 @@ def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=
                 a = np.round((x - i) * 256.0) / 256.0          # 8 fractional bits (ties are measure zero here)
                 T0, T1 = xf[min(127, max(0, i))].astype(np.float64), xf[min(127, max(0, i + 1))].astype(np.float64)
                 smp = (1 - a) * T0 + a * T1
+                if grad:      # exabrick.cu:999-1008: un-normalised quotient-rule gradient, shading by |cos| to the viewer
+                    g = sw * sd - swv * sdc
+                    if np.sqrt(np.dot(g, g)) > 1e-6:
+                        dd = d.astype(np.float64)
+                        smp[:3] = smp[:3] * (abs(np.dot(-dd, g)) / np.sqrt(np.dot(g, g) * np.dot(dd, dd)))
                 alpha = 1.0 - (1.0 - smp[3] * opacity_scale) ** float(Dt)
                 k = (1.0 - float(pix[3])) * alpha
                 pix = (pix.astype(np.float64) + k * np.array([smp[0], smp[1], smp[2], 1.0])).astype(f)
