@@ -346,7 +346,7 @@ def test_contour_plane_colour_and_shading():
     assert st["segments"] > 0                    # contour planes switch space skipping off: the volume is still walked
 
 
-def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0, grad=False):
+def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0, grad=False, info=None):
     """SURVEY.md Appendix A for a ONE-region, one-brick, level-0 scene without gradient shading, written from the spec
     in numpy float32 — independent of oracle/exa_oracle.c: LCG jitter, pinhole ray, slab test against the region
     domain (bounds +- half a cell), first sample at the first (off+i)*dt >= t0, midpoint sampling with partial first
@@ -423,6 +423,10 @@ def _pixel_from_spec(sc, vol, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=
                 smp = (1 - a) * T0 + a * T1
                 if grad:      # exabrick.cu:999-1008: un-normalised quotient-rule gradient, shading by |cos| to the viewer
                     g = sw * sd - swv * sdc
+                    # where the field is nearly flat the difference cancels almost completely and the DIRECTION of g is
+                    # rounding noise (float32 in the oracle, float64 here): such samples cannot be compared
+                    if info is not None and np.abs(g).max() < 1e-3 * (np.abs(sw * sd) + np.abs(swv * sdc)).max():
+                        info["ill_conditioned"] = info.get("ill_conditioned", 0) + 1
                     if np.sqrt(np.dot(g, g)) > 1e-6:
                         dd = d.astype(np.float64)
                         smp[:3] = smp[:3] * (abs(np.dot(-dd, g)) / np.sqrt(np.dot(g, g) * np.dot(dd, dd)))
