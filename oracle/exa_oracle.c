@@ -5,7 +5,11 @@
  * IEEE binary32 operations, exactly as written.
  *
  * PARITY STATUS: parity unpinned vs the real OptiX renderer (no goldens exist
- * upstream); pinned by analytic KATs and committed oracle-generated fixtures.
+ * upstream); pinned by analytic KATs, committed oracle-generated fixtures, and
+ * four independent numpy restatements of the reference's text (one-region DVR
+ * pixel incl. gradient shading, the region loop on the hat-basis definition, the
+ * implicit iso-surface, the hat-basis sample) swept over thousands of seeded
+ * random scenes (tests/fuzz_oracle.py, tests/fuzz_spec*.py).
  */
 #include "exa_oracle.h"
 
