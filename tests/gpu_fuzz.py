@@ -1,5 +1,5 @@
 """Sweep of seeded random parity cases on a GPU box (not collected by pytest):
-    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids | --many | --deep | --domains] [--keep-going]
+    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids | --many | --deep | --domains] [--clip] [--keep-going]
 For each seed: the oracle against the HIP module through the C ABI, both walks (kd, LBVH), library powf
 (`fast_math = 0`): accumulation buffer within the tolerance of tests/common.py, RGBA8 within 1 LSB, identical work
 counters, no slab-test mismatch; and the shipped kernel (counting off, `fast_math` 0 and 1 defaults) equal to the counting
@@ -16,7 +16,7 @@ from fuzz_cases import random_case, random_deep_case, random_rich_case
 STAT_KEYS = ["segments", "sample_evals", "samples", "brick_visits", "corner_loads", "iso_segments", "iso_evals"]
 
 
-def check(seed, rich=False):
+def check(seed, rich=False, clipbox=False):
     """list of failure strings (empty = pass)"""
     bad = []
     frames = 1
@@ -26,6 +26,17 @@ def check(seed, rich=False):
         case, desc = random_deep_case(seed)
     else:
         case, desc = random_case(seed, grids=(rich == "grids"), many=(rich == "many"))     # also "domains"
+    if clipbox:
+        # a clip box on top of the second family (world space; with a voxel-space transform the world is the unit cube at -p/ext)
+        rng = np.random.default_rng(0xC11B000 + seed)
+        if case.xfm is not None:
+            wlo = -np.asarray(case.xfm["p"]) / np.array([case.xfm["vx"][0], case.xfm["vy"][1], case.xfm["vz"][2]])
+            whi = wlo + 1.0
+        else:
+            wlo, whi = (np.asarray(v, dtype=np.float64) for v in case.scene.bounds())
+        clo = wlo + rng.uniform(0.0, 0.45, 3) * (whi - wlo)
+        case.clip = (list(clo), list(clo + rng.uniform(0.25, 0.6, 3) * (whi - wlo)))
+        desc["clip"] = case.clip
     if rich == "domains":
         # the TF domain per channel: degenerate, reversed, very narrow, far wider than the data, off to one side
         rng = np.random.default_rng(0xD0A1000 + seed)
@@ -86,7 +97,7 @@ if __name__ == "__main__":
     rich = True if "--rich" in sys.argv else ("grids" if "--grids" in sys.argv else ("many" if "--many" in sys.argv else ("deep" if "--deep" in sys.argv else ("domains" if "--domains" in sys.argv else False))))
     fails, t0 = 0, time.time()
     for seed in range(first, last + 1):
-        bad, desc = check(seed, rich)
+        bad, desc = check(seed, rich, clipbox=("--clip" in sys.argv))
         if bad:
             fails += 1
             print(f"FAIL seed {seed}: {desc}", flush=True)
