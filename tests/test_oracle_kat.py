@@ -480,15 +480,17 @@ def test_oracle_pixels_follow_the_spec_on_seeded_random_one_brick_scenes(seed):
     assert not bad, desc
 
 
-def _iso_pixel_from_spec(vol, cam, xf, dom, W, H, px, py, iso, grad_iso, dt=0.5, frame=0, info=None):
+def _iso_pixel_from_spec(vol, cam, xf, dom, W, H, px, py, iso, grad_iso, dt=0.5, frame=0, info=None, ao_length=None):
     """the implicit iso-surface of ONE level-0 brick, written from exabrick.cu:1019-1110 (the integration functor),
-    :1187-1253 (isoIntegrateBrick), :1408-1460 (traceIsoRay) and :1601-1652 (shading of the hit) in numpy — independent of
-    oracle/exa_oracle.c.  The TF is taken to be transparent (alpha 0), so the pixel is the shaded surface colour:
-    stepping as in the DVR march with offset 0; a crossing between consecutive valid samples (last <= iso <= v or the
-    reverse) is re-sampled at the distance-weighted point between them, coloured by the TF at the value found THERE,
+    :1187-1253 (isoIntegrateBrick), :1408-1460 (traceIsoRay) and :1601-1652 (shading of the hit, AO rays) in numpy —
+    independent of oracle/exa_oracle.c.  The TF is taken to be transparent (alpha 0), so the pixel is the shaded surface
+    colour: stepping as in the DVR march with offset 0; a crossing between consecutive valid samples (last <= iso <= v or
+    the reverse) is re-sampled at the distance-weighted point between them, coloured by the TF at the value found THERE,
     shaded by .3 + .7 |cos| of the normalised gradient there when gradient shading is on; later crossings in the same
     brick no longer change the colour (the surface is opaque) but do overwrite the hit distance and the gradient the
-    caller shades with (|cos| once more, :1646-1650)."""
+    caller shades with (|cos| once more, :1646-1650).  ao_length: two cosine-distributed AO rays from the hit point
+    (u1, u2 drawn per ray right after the two pixel-jitter draws; tmin 1e-4, tmax = ao_length), each a traceIsoRay of its
+    own; the colour is scaled by 1 - hits/2."""
     f = np.float32
     def lcg_init(v0, v1):
         M, s0 = 0xFFFFFFFF, 0
@@ -502,11 +504,12 @@ def _iso_pixel_from_spec(vol, cam, xf, dom, W, H, px, py, iso, grad_iso, dt=0.5,
         state[0] = (1664525 * state[0] + 1013904223) & 0xFFFFFFFF
         return f((state[0] & 0xFFFFFF) / float(1 << 24))
     sx_, sy_ = f(px) + rnd(), f(py) + rnd()
-    d = (cam["dir00"] + sx_ * cam["dirDu"]).astype(f)
-    d = (d + sy_ * cam["dirDv"]).astype(f)
-    d = (d * (f(1.0) / np.sqrt(np.dot(d, d).astype(f), dtype=f))).astype(f)
-    o = cam["pos"].astype(f)
+    d0 = (cam["dir00"] + sx_ * cam["dirDu"]).astype(f)
+    d0 = (d0 + sy_ * cam["dirDv"]).astype(f)
+    d0 = (d0 * (f(1.0) / np.sqrt(np.dot(d0, d0).astype(f), dtype=f))).astype(f)
+    o0 = cam["pos"].astype(f)
     n = vol.shape[0]
+    active = float(vol.min()) <= iso <= float(vol.max())          # the region is iso-active (exabrick.cu:391-397)
 
     def sample_at(p):
         q = (np.asarray(p, dtype=np.float64) - 0.5)
@@ -545,60 +548,110 @@ def _iso_pixel_from_spec(vol, cam, xf, dom, W, H, px, py, iso, grad_iso, dt=0.5,
         T0, T1 = xf[min(127, max(0, i))].astype(np.float64), xf[min(127, max(0, i + 1))].astype(np.float64)
         return ((1 - a) * T0 + a * T1)[:3]
 
-    lo, hi = f(-0.5), f(n + 0.5)
-    with np.errstate(divide="ignore", invalid="ignore"):
-        tl, th = ((lo - o) / d).astype(f), ((hi - o) / d).astype(f)
-    t0 = max(f(1e-6), np.fmax(np.fmax(np.fmin(tl, th)[0], np.fmin(tl, th)[1]), np.fmin(tl, th)[2]))
-    t1 = min(f(1e8), np.fmin(np.fmin(np.fmax(tl, th)[0], np.fmax(tl, th)[1]), np.fmax(tl, th)[2]))
-    colour, t_hit, gradient = None, -1.0, np.zeros(3)
-    if t0 < t1 and float(vol.min()) <= iso <= float(vol.max()):      # the region is iso-active (exabrick.cu:391-397)
-        step = f(dt)
-        i0 = int(np.ceil(f(t0 / step)))
-        t_i = f(f(i0) * step)
-        while f(t_i - step) >= t0:
-            t_i = f(t_i - step)
-        while t_i < t0:
-            t_i = f(t_i + step)
-        t_last, last_v, last_ts = t0, None, 0.0
-        while True:
-            t_next = min(t_i, t1)
-            ts = f(f(0.5) * f(t_next + t_last))
-            t_last = t_next
-            ok, v, g = sample_at((o + ts * d).astype(f))
-            if ok:
-                if last_v is not None and ((last_v <= iso <= v) or (last_v >= iso >= v)):
-                    d1, d2 = abs(last_v - iso), abs(v - iso)
-                    if d1 + d2 == 0.0:
-                        if info is not None:
-                            info["degenerate"] = 1                   # 0/0 in the reference (a constant field at the iso value)
-                        return np.zeros(3, dtype=f)
-                    w1, w2 = 1.0 - d1 / (d1 + d2), 1.0 - d2 / (d1 + d2)
-                    tavg = last_ts * w1 + float(ts) * w2
-                    isopt = o.astype(np.float64) + tavg * d.astype(np.float64)
-                    ok2, v2, g2 = sample_at(isopt)
-                    rgb = tf_rgb(v2) if ok2 else np.array([1.0, 0.0, 0.0])
-                    grad = np.zeros(3)
-                    if grad_iso and ok2:
-                        nrm = np.sqrt(np.dot(g2, g2))
-                        grad = g2 / nrm if nrm > 0 else np.full(3, np.nan)
-                        if np.dot(grad, d.astype(np.float64)) > 0:
-                            grad = -grad
-                    if not np.isfinite(grad).all():
-                        grad = np.zeros(3)
-                    if np.sqrt(np.dot(grad, grad)) > 0:
-                        rgb = rgb * (0.3 + 0.7 * abs(np.dot(-d.astype(np.float64), grad)) / np.sqrt(np.dot(grad, grad)))
-                    if colour is None:
-                        colour = rgb                                 # opaque: later crossings add (1 - 1) * ...
-                    t_hit, gradient = tavg, grad
-                last_v, last_ts = v, float(ts)
-            if t_next >= t1:
+    def trace(o, d, tmin, tmax):
+        """traceIsoRay (voxel space = world space): (colour, t_hit, gradient) or (None, -1, 0).  Faithful to the trace loop:
+        dt_scale = |d| as float32 (an ulp off 1 for a 'normalised' direction), d re-normalised, tmax multiplied by dt_scale
+        before EVERY trace (:1434), the region's exit reported clamped to that tmax and the next trace starting just behind
+        it — so a ray of finite length may see a sliver of the same region again; the functor state persists."""
+        dt_scale = f(np.sqrt(f(f(f(d[0] * d[0]) + f(d[1] * d[1])) + f(d[2] * d[2])), dtype=f))
+        d = (d * (f(1.0) / dt_scale)).astype(f)
+        lo, hi = f(-0.5), f(n + 0.5)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            tl, th = ((lo - o) / d).astype(f), ((hi - o) / d).astype(f)
+        near = np.fmax(np.fmax(np.fmin(tl, th)[0], np.fmin(tl, th)[1]), np.fmin(tl, th)[2])
+        far = np.fmin(np.fmin(np.fmax(tl, th)[0], np.fmax(tl, th)[1]), np.fmax(tl, th)[2])
+        already, tmax_cur = f(dt_scale * f(tmin)), f(tmax)
+        last_v, last_ts = None, 0.0
+        for _ in range(64):
+            with np.errstate(over="ignore"):
+                tmax_cur = f(tmax_cur * dt_scale)
+            t0, t1 = max(already, near), min(tmax_cur, far)
+            if not (t0 < t1 and active):
                 break
-            t_i = f(t_i + step)
+            if info is not None and tmax_cur < far:
+                # the ray ends inside the region: whether the next trace sees a sliver of it again depends on |d| having
+                # rounded above or below 1 — an ulp of the direction, which float64 here cannot reproduce
+                info["tmax_sliver"] = 1
+            colour, t_hit, gradient = None, -1.0, np.zeros(3)
+            step = f(dt)
+            i0 = int(np.ceil(f(t0 / step)))
+            t_i = f(f(i0) * step)
+            while f(t_i - step) >= t0:
+                t_i = f(t_i - step)
+            while t_i < t0:
+                t_i = f(t_i + step)
+            t_last = t0
+            while True:
+                t_next = min(t_i, t1)
+                ts = f(f(0.5) * f(t_next + t_last))
+                t_last = t_next
+                ok, v, g = sample_at((o + ts * d).astype(f))
+                if info is not None and "debug" in info:
+                    info["debug"].append((float(tmin), float(ts), ok, v))
+                if ok:
+                    if info is not None and abs(v - iso) < 5e-5:
+                        info["marginal_crossing"] = 1                 # float32 vs float64 may see the crossing differently
+                    if last_v is not None and ((last_v <= iso <= v) or (last_v >= iso >= v)):
+                        d1, d2 = abs(last_v - iso), abs(v - iso)
+                        if d1 + d2 == 0.0:
+                            if info is not None:
+                                info["degenerate"] = 1               # 0/0 in the reference (a constant field at the iso value)
+                            return None, -1.0, np.zeros(3)
+                        w1, w2 = 1.0 - d1 / (d1 + d2), 1.0 - d2 / (d1 + d2)
+                        tavg = last_ts * w1 + float(ts) * w2
+                        isopt = o.astype(np.float64) + tavg * d.astype(np.float64)
+                        ok2, v2, g2 = sample_at(isopt)
+                        rgb = tf_rgb(v2) if ok2 else np.array([1.0, 0.0, 0.0])
+                        grad = np.zeros(3)
+                        if grad_iso and ok2:
+                            nrm = np.sqrt(np.dot(g2, g2))
+                            grad = g2 / nrm if nrm > 0 else np.full(3, np.nan)
+                            if np.dot(grad, d.astype(np.float64)) > 0:
+                                grad = -grad
+                        if not np.isfinite(grad).all():
+                            grad = np.zeros(3)
+                        if np.sqrt(np.dot(grad, grad)) > 0:
+                            rgb = rgb * (0.3 + 0.7 * abs(np.dot(-d.astype(np.float64), grad)) / np.sqrt(np.dot(grad, grad)))
+                        if colour is None:
+                            colour = rgb                             # opaque: later crossings add (1 - 1) * ...
+                        t_hit, gradient = tavg, grad
+                    last_v, last_ts = v, float(ts)
+                if t_next >= t1:
+                    break
+                t_i = f(t_i + step)
+            if colour is not None:
+                return colour, t_hit / float(dt_scale), gradient
+            already = f(t1 * f(1.0000001))
+        return None, -1.0, np.zeros(3)
+
+    colour, t_hit, gradient = trace(o0, d0, 1e-6, 1e8)
     if colour is None:
         return np.zeros(3, dtype=f)
     nrm = np.sqrt(np.dot(gradient, gradient))
     if grad_iso and nrm > 0:
-        colour = colour * abs(np.dot(d.astype(np.float64), gradient / nrm))
+        Ng = gradient / nrm
+        shadow = 0.0
+        if ao_length is not None:
+            isect = (o0.astype(np.float64) + d0.astype(np.float64) * t_hit)
+            w = Ng
+            if info is not None and abs(abs(w[0]) - abs(w[1])) < 1e-5:
+                info["basis_tie"] = 1         # |w.x| > |w.y| picks the tangent frame: a rounding matter when both are ~equal (or ~0)
+            v_ = np.array([-w[2], 0.0, w[0]]) if abs(w[0]) > abs(w[1]) else np.array([0.0, w[2], -w[1]])
+            v_ = v_ / np.sqrt(np.dot(v_, v_))
+            u_ = np.cross(v_, w)
+            hits = 0
+            for _ in range(2):
+                u1, u2 = float(rnd()), float(rnd())
+                r, theta = np.sqrt(u1), 2.0 * np.pi * u2
+                sp = np.array([r * np.cos(theta), r * np.sin(theta), np.sqrt(1.0 - u1)])
+                dirv = sp[0] * u_ + sp[1] * v_ + sp[2] * w
+                dirv = dirv / np.sqrt(np.dot(dirv, dirv))
+                if info is not None and "debug" in info:
+                    info["debug"].append(("ao", isect.tolist(), dirv.tolist(), u1, u2, Ng.tolist(), t_hit))
+                c2, _, _ = trace(isect.astype(f), dirv.astype(f), 1e-4, ao_length)
+                hits += int(c2 is not None)
+            shadow = hits / 2.0
+        colour = colour * abs(np.dot(d0.astype(np.float64), Ng)) * (1.0 - shadow)
     return colour.astype(f)
 
 
