@@ -666,7 +666,7 @@ def test_oracle_iso_surface_follows_the_functor_spec_on_seeded_random_one_brick_
     assert desc["compared"] > 10
 
 
-def _pixel_from_spec_regions(S, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0, grad=False, info=None):
+def _pixel_from_spec_regions(S, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0, grad=False, info=None, clip=None):
     """SURVEY.md Appendix A for a MULTI-region scene of one channel, space skipping off: the region loop of renderFrame /
     traceVolumeRay (closest region whose slab interval, clamped to [done, tmax], is not empty; `done = t1 * 1.0000001f`
     afterwards), per-region step `dt * finestLevelCellWidth`, first sample on the global lattice (off + i) * dt, midpoint
@@ -698,9 +698,14 @@ def _pixel_from_spec_regions(S, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scal
     near = np.fmax(np.fmax(np.fmin(tl, th)[:, 0], np.fmin(tl, th)[:, 1]), np.fmin(tl, th)[:, 2])
     far = np.fmin(np.fmin(np.fmax(tl, th)[:, 0], np.fmax(tl, th)[:, 1]), np.fmax(tl, th)[:, 2])
     pix = np.zeros(4, dtype=f)
-    done = f(1e-6)
+    done, tmax = f(1e-6), f(1e8)
+    if clip is not None:                                           # clipRay (:1258-1265): boxTest narrows [tmin, tmax]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            cl, ch = ((np.asarray(clip[0], dtype=f) - o) / d).astype(f), ((np.asarray(clip[1], dtype=f) - o) / d).astype(f)
+        done = max(done, np.fmax(np.fmax(np.fmin(cl, ch)[0], np.fmin(cl, ch)[1]), np.fmin(cl, ch)[2]))
+        tmax = min(tmax, np.fmin(np.fmin(np.fmax(cl, ch)[0], np.fmax(cl, ch)[1]), np.fmax(cl, ch)[2]))
     for _ in range(len(R) + 2):
-        t0s, t1s = np.maximum(near, done), np.minimum(far, f(1e8))
+        t0s, t1s = np.maximum(near, done), np.minimum(far, tmax)
         hit = np.nonzero(t0s < t1s)[0]
         if len(hit) == 0:
             break
@@ -747,7 +752,7 @@ def _pixel_from_spec_regions(S, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scal
         if pix[3] >= f(0.98):
             pix = np.array([pix[0] * pix[3], pix[1] * pix[3], pix[2] * pix[3], 1.0], dtype=f)
             break
-        done = f(f(far[r] if far[r] < f(1e8) else f(1e8)) * f(1.0000001))
+        done = f(f(far[r] if far[r] < tmax else tmax) * f(1.0000001))
     return (pix[3] * pix[:3]).astype(f)
 
 
