@@ -765,3 +765,68 @@ def test_oracle_region_loop_follows_the_spec_on_seeded_random_multi_region_scene
     bad, desc = check(seed)
     assert not bad, desc
     assert desc["compared"] > 10
+
+
+def _hat_value(S, region, p, chan):
+    """value of channel `chan` at p from the definition of the basis (see _hat_reconstruction), or None"""
+    B, R, L = S.bricks(), S.regions()[region], S.leaflist()
+    sc = S.scalars()[chan * S.total_cells:(chan + 1) * S.total_cells]
+    sw = swv = 0.0
+    for b in L[R["leafListBegin"]:R["leafListBegin"] + R["leafListSize"]]:
+        br = B[b]
+        cw = float(1 << int(br["level"]))
+        sx, sy, sz = (int(v) for v in br["size"])
+        idx = np.arange(sx * sy * sz)
+        ctr = np.stack([idx % sx, (idx // sx) % sy, idx // (sx * sy)], axis=1) * cw + np.asarray(br["lower"], dtype=np.float64) + 0.5 * cw
+        w = np.maximum(0.0, 1.0 - np.abs((np.asarray(p, dtype=np.float64)[None] - ctr) / cw)).prod(axis=1)
+        sw += w.sum(); swv += (w * sc[int(br["begin"]) + idx].astype(np.float64)).sum()
+    return None if sw <= 1e-20 else swv / sw
+
+
+def _tracer_step_from_spec(S, chans, steplen, p, info=None):
+    """one RK4 step of the streamline tracer (exabrick.cu:1531-1574) from the definition: the direction at a point is the
+    three tracer channels sampled in the region that contains it (sampleDirection, :945-963: a degenerate ray finds the
+    region), k_i = direction * steplen, p += (k1 + 2 k2 + 2 k3 + k4) / 6; the trace ends (2e10) when a direction cannot be
+    sampled, the point leaves the world bounds or does not move."""
+    R = S.regions()
+    lo, hi = S.voxel_bounds()
+
+    def direction(q):
+        inside = np.nonzero(((q >= R["dom_lo"]) & (q <= R["dom_hi"])).all(axis=1))[0]
+        strictly = np.nonzero(((q > R["dom_lo"] + 1e-4) & (q < R["dom_hi"] - 1e-4)).all(axis=1))[0]
+        if len(inside) != len(strictly) and info is not None:
+            info["on_a_region_face"] = 1                      # which region a degenerate ray reports there is OptiX's choice
+        if len(inside) == 0:
+            return None
+        v = [_hat_value(S, int(inside[0]), q, c) for c in chans]
+        return None if any(x is None for x in v) else np.array(v)
+
+    p = np.asarray(p, dtype=np.float64)
+    if not p[0] < 2e10:
+        return np.full(3, 2e10)
+    valid = True
+    ks, q = [], p
+    for i, h in enumerate((0.5, 0.5, 1.0, None)):
+        dvec = direction(q)
+        if dvec is None:
+            valid = False
+            dvec = np.zeros(3)
+        k = dvec * steplen
+        ks.append(k)
+        if h is not None:
+            q = p + k * h
+    pn = p + (1.0 / 6.0) * (ks[0] + 2.0 * ks[1] + 2.0 * ks[2] + ks[3])
+    if info is not None and (np.abs(pn - lo).min() < 1e-3 or np.abs(pn - hi).min() < 1e-3):
+        info["at_the_world_bounds"] = 1
+    if not valid or not ((pn >= lo) & (pn <= hi)).all() or np.sqrt(((pn - p) ** 2).sum()) < 1e-10:
+        return np.full(3, 2e10)
+    return pn
+
+
+@pytest.mark.parametrize("seed", range(15))
+def test_oracle_tracer_follows_the_rk4_spec_on_seeded_random_scenes(seed):
+    """tests/fuzz_spec_tracer.py: every RK4 step of every trace redone from the definition of the basis (directions =
+    the three tracer channels at the point, termination rules of exabrick.cu:1566-1568); 3 000 seeds, 46 000 steps"""
+    from fuzz_spec_tracer import check
+    bad, desc = check(seed)
+    assert not bad, desc
