@@ -2,7 +2,7 @@
 MULTI-region scenes (CPU only):  python tests/fuzz_spec_regions.py FIRST LAST
 Random partitions into bricks of any shape and level (holes, level jumps), space skipping off, smooth TF, gradient shading
 off (the un-normalised gradient of a level boundary is ill-conditioned where the field is flat; the gradient itself is
-checked by the hat-basis sweep), random camera / step / opacity scale / frame id / clip box; 24 random pixels per case."""
+checked by the hat-basis sweep), random camera / step / opacity scale / frame id / clip box / a second primary channel; 24 random pixels per case."""
 import sys
 import time
 
@@ -39,15 +39,24 @@ def check(seed):
     if rng.uniform() < 0.3:
         clo = rng.uniform(0.0, 0.4, 3) * ext
         clip = (list(clo), list(clo + rng.uniform(0.3, 0.6, 3) * ext))
-    case = Case(sc, W=W, H=H, grad=0, xf=xf, xf_domains=[(0.0, 1.0)], dt=dt, opacity_scale=osc, frameID=frame, camera=cam, space_skipping=0,
-                clip=clip)
+    more = []
+    if rng.uniform() < 0.35:                                    # a second primary channel with its own TF and domain
+        k = rng.uniform(0.05, 0.4, 3)
+        scenes.with_extra_field(sc, lambda ctr: 0.5 + 0.5 * np.sin(ctr @ k))
+        xf2 = harness.default_xf()
+        xf2[:, 3] = (0.3 * (1.0 - t)).astype(np.float32)
+        xf2[:, :3] = xf2[:, ::-1][:, 1:4]
+        more.append((xf2, (0.1, 0.9)))
+    case = Case(sc, W=W, H=H, grad=0, xf=[xf] + [m[0] for m in more], xf_domains=[(0.0, 1.0)] + [m[1] for m in more], dt=dt,
+                opacity_scale=osc, frameID=frame, camera=cam, space_skipping=0, clip=clip)
     rgba, acc, st = case.run_oracle(nthreads=2)
     S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
-    tol = 3e-5 + 2.0 * float(np.abs(np.diff(xf, axis=0)).max()) * osc / 256.0
+    tol = 3e-5 + 2.0 * max(float(np.abs(np.diff(x_, axis=0)).max()) for x_ in [xf] + [m[0] for m in more]) * osc / 256.0
     worst, at_px, compared, lit = 0.0, None, 0, 0
     for px, py in zip(rng.integers(0, W, 24), rng.integers(0, H, 24)):
         info = {}
-        want = _pixel_from_spec_regions(S, cam, xf, (0.0, 1.0), W, H, int(px), int(py), dt=dt, opacity_scale=osc, frame=frame, info=info, clip=clip)
+        want = _pixel_from_spec_regions(S, cam, xf, (0.0, 1.0), W, H, int(px), int(py), dt=dt, opacity_scale=osc, frame=frame, info=info, clip=clip,
+                                        more_channels=more)
         if info:
             continue
         compared += 1

@@ -666,7 +666,8 @@ def test_oracle_iso_surface_follows_the_functor_spec_on_seeded_random_one_brick_
     assert desc["compared"] > 10
 
 
-def _pixel_from_spec_regions(S, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0, grad=False, info=None, clip=None):
+def _pixel_from_spec_regions(S, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scale=1.0, frame=0, grad=False, info=None, clip=None,
+                             more_channels=()):
     """SURVEY.md Appendix A for a MULTI-region scene of one channel, space skipping off: the region loop of renderFrame /
     traceVolumeRay (closest region whose slab interval, clamped to [done, tmax], is not empty; `done = t1 * 1.0000001f`
     afterwards), per-region step `dt * finestLevelCellWidth`, first sample on the global lattice (off + i) * dt, midpoint
@@ -743,6 +744,21 @@ def _pixel_from_spec_regions(S, cam, xf, dom, W, H, px, py, dt=0.5, opacity_scal
                     if np.sqrt(np.dot(g, g)) > flcw * 1e-6:
                         dd = d.astype(np.float64)
                         smp[:3] = smp[:3] * (abs(np.dot(-dd, g)) / np.sqrt(np.dot(g, g) * np.dot(dd, dd)))
+                alpha = 1.0 - (1.0 - smp[3] * opacity_scale) ** float(Dt)
+                k = (1.0 - float(pix[3])) * alpha
+                pix = (pix.astype(np.float64) + k * np.array([smp[0], smp[1], smp[2], 1.0])).astype(f)
+            # further primary channels of the same sample, each through its own TF, composited in channel order; the
+            # termination test comes after the channel loop (exabrick.cu:1166-1181)
+            for c, (xf_c, dom_c) in enumerate(more_channels, start=1):
+                vc = _hat_value(S, r, p, c)
+                if vc is None or Dt == 0:
+                    continue
+                s_ = 127.0 * (vc - dom_c[0]) / ((dom_c[1] - dom_c[0]) + 1e-20)
+                u_ = min(127.0, max(0.0, s_ + 0.5)) / 127.0
+                x_ = u_ * 128.0 - 0.5
+                i_ = int(np.floor(x_))
+                a_ = np.round((x_ - i_) * 256.0) / 256.0
+                smp = (1 - a_) * xf_c[min(127, max(0, i_))].astype(np.float64) + a_ * xf_c[min(127, max(0, i_ + 1))].astype(np.float64)
                 alpha = 1.0 - (1.0 - smp[3] * opacity_scale) ** float(Dt)
                 k = (1.0 - float(pix[3])) * alpha
                 pix = (pix.astype(np.float64) + k * np.array([smp[0], smp[1], smp[2], 1.0])).astype(f)
