@@ -102,34 +102,42 @@ def spawn_ranks(n):
     return rc if rc >= 0 else 1
 
 
-MARCH_KERNEL_RE = r"renderFrame(Kd)?Kernel<.*, 0(, (true|false))?>"     # the shipped march: STATS template argument 0
+# the kernels of one frame: the shipped march (STATS template argument 0), its wide variants for critical tiles, and the
+# surfaces pre-pass (iso-surfaces, AO); the counting variants (STATS 1 / 2) are not part of a timed frame
+FRAME_KERNELS = {"march": r"renderFrame(Kd)?Kernel<.*, 0(, (true|false))?>",
+                 "march_wide": r"renderFrameKdWideKernel<",
+                 "surfaces_prepass": r"surfacePrepassKdKernel<0>"}
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "SQ_INSTS_VALU"))     # HBM reads alone (MI355X_MICROARCH.md: separate passes)
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0       # G wave64-VALU instructions / s: 1024 SIMDs, one every 2 cycles, 2.4 GHz
+F32_VECTOR_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 vector peak (FMA counted as 2)
 
 
-def pmc_means(csv_files, kernel_re):
-    """rocprofv3 counter_collection CSVs -> ({counter: mean over the dispatches of the kernels matching kernel_re}, number
-    of dispatches).  A dispatch's value is the sum of its rows (one row per counter instance: XCD, channel, ...)."""
+def pmc_frame_totals(csv_files, classes=FRAME_KERNELS):
+    """rocprofv3 counter_collection CSVs -> ({kernel class: {counter: mean per FRAME}}, frames).  A dispatch's value is the
+    sum of its rows (one row per counter instance: XCD, channel, ...); a frame is one dispatch of the "march" class, the
+    other classes' dispatches (wide tiles, surfaces pre-pass) belong to the frames they were launched with."""
     import csv
     import re
-    per = {}
+    tot, disp = {}, {}
     for f in csv_files:
         with open(f, newline="") as fh:
             for row in csv.DictReader(fh):
-                if re.search(kernel_re, row["Kernel_Name"]):
-                    key = (f, row["Dispatch_Id"], row["Counter_Name"])
-                    per[key] = per.get(key, 0.0) + float(row["Counter_Value"])
-    by_counter = {}
-    for (_, _, name), v in per.items():
-        by_counter.setdefault(name, []).append(v)
-    n = max((len(v) for v in by_counter.values()), default=0)
-    return {k: sum(v) / len(v) for k, v in by_counter.items()}, n
+                for cls, rx in classes.items():
+                    if re.search(rx, row["Kernel_Name"]):
+                        d = tot.setdefault(cls, {})
+                        d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                        disp.setdefault((cls, row["Counter_Name"]), set()).add((f, row["Dispatch_Id"]))
+                        break
+    frames = max((len(v) for (cls, _), v in disp.items() if cls == "march"), default=0)
+    if not frames:
+        return {}, 0
+    return {cls: {c: v / frames for c, v in d.items()} for cls, d in tot.items()}, frames
 
 
-def live_pmc(child_args, kernel_re, seconds=240.0):
-    """HBM bytes and VALU wave-instructions per launch of the march kernel, measured in THIS run: for each counter group
-    a child `rocprofv3 --pmc ... -- python3 bench.py <same workload> --steps 2` (counters only, no trace domains; the
-    parent is idle meanwhile).  Returns ({counter: mean per dispatch of the shipped kernel}, n_dispatches) or
-    (None, reason).  Counter values are summed over the instances of a dispatch (XCDs / channels)."""
+def live_pmc(child_args, seconds=300.0, extra_env=None):
+    """HBM bytes and VALU wave-instructions per frame, by kernel class, measured in THIS run: for each counter group a child
+    `rocprofv3 --pmc ... -- python3 bench.py <same workload> --steps 2` (counters only, no trace domains; the parent is
+    idle meanwhile).  Returns ({class: {counter: mean per frame}}, frames) or (None, reason)."""
     import glob
     import shutil
     import signal
@@ -140,9 +148,11 @@ def live_pmc(child_args, kernel_re, seconds=240.0):
         return None, "rocprofv3 not found"
     out_dir = tempfile.mkdtemp(prefix="exa_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", EXA_BENCH_CPU_THREADS="2")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "EXA_BENCH_FORCE_DIST", "EXA_BENCH_SHARD"):
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+              "EXA_BENCH_FORCE_DIST", "EXA_BENCH_SHARD", "EXA_BENCH_SPAWNED", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
-    vals, n_disp = {}, 0
+    env.update(extra_env or {})
+    merged, frames = {}, 0
     try:
         for i, counters in enumerate(PMC_PASSES):
             cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(out_dir, f"pass{i}"), "--",
@@ -158,15 +168,20 @@ def live_pmc(child_args, kernel_re, seconds=240.0):
             if p.returncode != 0:
                 tail = (err or b"").decode(errors="replace").strip().splitlines()[-1:] or [""]
                 return None, f"pass {i} ({' '.join(counters)}) exited with {p.returncode}: {tail[0][:200]}"
-            means, n_disp = pmc_means(glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True),
-                                      kernel_re)
+            tot, frames = pmc_frame_totals(glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True))
             for c in counters:
-                if c not in means:
+                if c not in tot.get("march", {}):
                     return None, f"pass {i}: no dispatch of the march kernel carries {c}"
-                vals[c] = means[c]
-        return vals, n_disp
+            for cls, d in tot.items():
+                merged.setdefault(cls, {}).update({c: d[c] for c in counters if c in d})
+        return merged, frames
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
+
+
+def useful_flops(st, grad):
+    """SURVEY 8(d), informational: ~60 flop per addBasisFunctions call (+~70 with derivatives), ~40 per integrateVolume"""
+    return st["brick_visits"] * (60.0 + (70.0 if grad else 0.0)) + st["samples"] * 40.0
 
 
 def main():
@@ -453,13 +468,59 @@ def main():
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    # after the timed region every handle renders one synchronous frame: a synchronous render reads the loop-guard flag
+    # (frames queued with async_ do not), so a guard that tripped inside the timed region fails the run here
+    torch.cuda.synchronize()
+    for Rk in Rs[1:]:
+        Rk.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
     if F > 1:
         # kernel time per launch (HIP events on the launch stream) on synchronous frames after the timed region: with
         # several frames in flight a launch shares the GPU with its neighbours and its own duration says little
-        torch.cuda.synchronize()
         for _ in range(min(5, max(2, args.steps))):
             R.render(device_ptr=shards[0].data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
             kernel_ms.append(R.stats()["kernel_ms"])
+
+    # ---- latency of a lone frame (F = 1): march, gather, untile, host waits — what the reference's synchronous viewer
+    #      loop would see.  With one frame in flight the timed region above already is that; with several, measure it
+    #      here with the critical tiles marched wide (wide_march = 1, the lone-frame default) ----
+    latency_ms = None
+    if F > 1:
+        R.setOption("wide_march", 1)
+        cur = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):                          # layout changed: cost feedback measures, re-orders, assigns wide tiles
+            R.render(device_ptr=shards[0].data_ptr(), stream=cur)
+
+        def lone_frame():
+            for f in range(args.spp):
+                if args.spp > 1:
+                    R.updateFrameID(f)
+                R.render(device_ptr=shards[0].data_ptr(), stream=cur)
+            if use_dist:
+                if backend == "nccl":
+                    dist.gather(shards[0], gathered, dst=0)
+                else:
+                    host = shards[0].cpu()
+                    hl = [torch.zeros_like(host) for _ in range(world)] if rank == 0 else None
+                    dist.gather(host, hl, dst=0)
+                    if rank == 0:
+                        gathered_flat.copy_(torch.cat(hl))
+                if rank == 0:
+                    untile(cur)
+            torch.cuda.synchronize()
+        lone_frame()
+        if use_dist:
+            dist.barrier()
+        n_lat = max(2, min(args.steps, 20))
+        t_l = time.perf_counter()
+        for _ in range(n_lat):
+            lone_frame()
+        if use_dist:
+            dist.barrier()
+        el_l = torch.tensor([time.perf_counter() - t_l], dtype=torch.float64, device=cdev)
+        if use_dist:
+            dist.all_reduce(el_l, op=dist.ReduceOp.MAX)
+        latency_ms = 1000.0 * float(el_l.item()) / n_lat
+        R.setOption("wide_march", 0)
 
     # aggregate per-rank work counters and kernel time
     agg = torch.tensor([st["samples"], st["brick_visits"], st["corner_loads"], st["segments"], st["nodes_visited"],
@@ -473,8 +534,6 @@ def main():
     if rank == 0:
         fps = args.steps / elapsed
         k_ms = float(np.mean(kernel_ms))                   # this rank's launches (HIP events on the launch stream)
-        B = algorithmic_bytes(st, st["pixels"], 0)         # per launch of this rank
-        achieved = B / (k_ms * 1e-3) / 1e9
         cfg = scenes.CONFIGS[args.config]
         out = {
             "metric": f"frames/sec at {W}^2 DVR{'+iso' if args.iso is not None else ''}{'+AO' if args.ao else ''}"
@@ -499,66 +558,52 @@ def main():
                                     f"{', overlapped with the next frame' if pipelined else ''}" if use_dist else ""),
                        "backend": backend if use_dist else None,
                        "samples_per_frame": samples_total, "kernel_ms_max_over_ranks": float(kmax.item())},
-            # Three views of the same launch: `achieved`/`frac` is SURVEY 8(d)'s formula — bytes the
-            # lanes REQUEST (most are served by L1/L2) over kernel time, against the HBM peak; `hbm_measured` is what
-            # reaches HBM according to the PMC counters; `valu_issue` is the resource that binds the kernel.
-            "roofline": {"bound": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "renderFrameKdKernel" if args.accel else "renderFrameKernel", "kernel_ms": k_ms,
-                         "algorithmic_bytes_per_launch": B,
-                         "bytes_breakdown": {"brick_records_and_leaf_entries": 36 * st["brick_visits"],
-                                             "cell_scalars": 4 * st["corner_loads"],
-                                             "region_records": 44 * st["segments"],
-                                             "accel_nodes": st.get("node_bytes", 64) * st["nodes_visited"],
-                                             "framebuffer": 20 * st["pixels"]}},
+            "latency_ms": latency_ms if latency_ms is not None else 1000.0 * elapsed / args.steps,
         }
+        out["config"]["latency_ms"] = ("one frame at a time (march, gather, untile, host waits), wide march on: the figure "
+                                       "comparable with a 1-GPU line" if latency_ms is not None else "= ms_per_step (one frame in flight)")
+        # ---- roofline: the frame's launches against the resource that binds them.  No dense contraction on
+        #      this path (no MFMA) and the working set is cache-resident (HBM far from its peak), what limits the march is
+        #      vector-instruction issue: frac = measured wave64 VALU instructions / kernel time against 1024 SIMDs x one
+        #      VALU instruction per 2 cycles.  The HBM view (PMC bytes against 8 TB/s) and the useful-flop fraction stand
+        #      beside it.  SURVEY 8(d)'s byte formula counts what the LANES REQUEST (most of it served by L1/L2): it is kept
+        #      as requested_bytes and never turned into a fraction of the HBM peak. ----
+        B = algorithmic_bytes(st, st["pixels"], 0)         # per launch of this rank, frame 0
+        flops = useful_flops(st, not args.no_grad)
+        roof = {"bound": "valu_issue", "achieved": None, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": None,
+                "traffic": None,
+                "kernel": ("renderFrameKdKernel" if args.accel else "renderFrameKernel")
+                          + (" + surfacePrepassKdKernel" if (args.iso is not None and args.accel) else ""),
+                "kernel_ms": k_ms,
+                "peak_note": "256 CUs x 4 SIMDs x 1 wave64 VALU instruction / 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)",
+                "useful_flops_per_launch": flops,
+                "useful_flop_frac": flops / (k_ms * 1e-3) / (F32_VECTOR_PEAK_TFLOPS * 1e12),
+                "useful_flop_note": f"SURVEY 8(d) flop counts (60 per brick visit + 70 with derivatives, 40 per sample) / kernel time / "
+                                    f"{F32_VECTOR_PEAK_TFLOPS} TFLOP/s f32 vector peak; parity forbids FMA contraction, so 0.5 is this path's ceiling",
+                "requested_bytes": B,
+                "requested_bytes_note": "SURVEY 8(d) formula: bytes the lanes request per launch (36 B per brick visit, 4 B per cell, 44 B "
+                                        "per segment, node bytes, 20 B per pixel); served mostly by L1/L2, NOT an HBM figure",
+                "requested_bytes_breakdown": {"brick_records_and_leaf_entries": 36 * st["brick_visits"],
+                                              "cell_scalars": 4 * st["corner_loads"],
+                                              "region_records": 44 * (st["segments"] + st["iso_segments"]),
+                                              "accel_nodes": st.get("node_bytes", 64) * st["nodes_visited"],
+                                              "framebuffer": 20 * st["pixels"]}}
+        out["roofline"] = roof
         traffic_file = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         key = f"{args.config}@{args.scale}@{W}"
         traffic = vi = None
-        plain = world == 1 and not rehearse and not use_dist and args.iso is None and args.spp == 1
-        stock = args.camera == "default" and args.fields is None        # what profiles/hbm_traffic.json was measured on
+        stock = (world == 1 and not rehearse and args.iso is None and args.spp == 1 and not args.ao
+                 and args.camera == "default" and args.fields is None and not args.no_grad and not args.option)   # what profiles/hbm_traffic.json was measured on
         profiled = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
-        if plain and (args.pmc == "on" or (args.pmc == "auto" and want_cpu and not profiled)):
-            # live counters of this very workload: 2 * FETCH_SIZE + WRITE_SIZE (KiB; MI355X_MICROARCH.md: gfx950 counts
-            # a 128-B read request as 64 B) and SQ_INSTS_VALU, per launch of the shipped march kernel
-            child = ["--config", args.config, "--scale", str(args.scale), "--size", str(W), "--steps", "2", "--warmup", "1",
-                     "--tile-order", str(args.tile_order), "--accel", str(args.accel), "--cpu-baseline", "off", "--pmc", "off"]
-            child += ["--no-grad"] if args.no_grad else []
-            child += ["--camera", args.camera] + (["--fields", str(args.fields)] if args.fields is not None else [])
-            for kv in args.option:
-                child += ["--option", kv]
-            t = time.perf_counter()
-            vals, n = live_pmc(child, MARCH_KERNEL_RE)
-            if vals:
-                traffic = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
-                vi = vals["SQ_INSTS_VALU"]
-                out["roofline"]["pmc_source"] = (f"live: rocprofv3 --pmc passes {[' '.join(c) for c in PMC_PASSES]} run by this bench.py "
-                                                 f"on the same workload ({n} launches averaged, {time.perf_counter() - t:.0f}s); "
-                                                 f"traffic = 2*FETCH_SIZE({vals['FETCH_SIZE']:.6g} KiB) + WRITE_SIZE({vals['WRITE_SIZE']:.6g} KiB)")
-            else:
-                log(f"live PMC pass not available ({n}); using {traffic_file}")
-                out["roofline"]["pmc_live_error"] = str(n)
-        if traffic is None and os.path.exists(traffic_file) and world == 1 and args.iso is None and args.spp == 1 and stock:
+        if args.pmc == "on" or (args.pmc == "auto" and args.cpu_baseline == "auto" and not profiled):
+            out["_pmc_child"] = True          # measured below, after the process group is gone
+        elif os.path.exists(traffic_file) and stock:
             try:
                 tf = json.load(open(traffic_file))
                 traffic, vi = tf.get(key), tf.get(key + ":valu_wave_instructions")
-                out["roofline"]["pmc_source"] = tf.get(key + ":note")
+                roof["pmc_source"] = tf.get(key + ":note")
             except Exception as e:  # noqa: BLE001
                 log(f"could not read {traffic_file}: {e}")
-        out["roofline"]["traffic"] = traffic
-        if traffic:
-            gbs = traffic / (k_ms * 1e-3) / 1e9
-            out["roofline"]["hbm_measured"] = {"achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                                               "requested_over_fetched": B / traffic}
-        if vi:
-            # what bounds the kernel: vector-instruction issue.  A wave64 VALU instruction holds a SIMD
-            # for 2 cycles (MI355X_MICROARCH.md, wave scheduling); 256 CUs x 4 SIMDs at 2.4 GHz
-            floor_ms = vi * 2.0 / (256 * 4) / 2.4e9 * 1e3
-            out["roofline"]["valu_issue"] = {"wave_instructions": vi, "floor_ms": floor_ms, "frac": floor_ms / k_ms,
-                                             "peak": "1024 SIMDs x 1 wave64 VALU instruction / 2 cycles at 2.4 GHz",
-                                             "source": "SQ_INSTS_VALU, see pmc_source"}
-        if "valu_issue" not in out["roofline"]:
-            out["roofline"]["bound"] = "hbm"       # no counter file for this configuration: only the formula view
         if args.dump:
             img = (final if use_dist else shards[0]).cpu().numpy().view(np.uint32).reshape(H, W)
             harness.write_png(args.dump, img)
@@ -573,24 +618,28 @@ def main():
             harness.fill_frame_state(fs, cam, [scene.value_range], xfOpacityScale=1.0, frameID=0)
             P = po.Params(0.5, 1, 0, 0 if args.no_grad else 1, 1, 1, 1)
             cores = effective_cpus()
-            # calibrate on a 64x64 centre window (after a warm-up that spins the threads up),
-            # then size the crop for ~cpu-seconds of work
+            # SURVEY 8(d) protocol: mean of 5 renders after 1 warm-up.  Calibrate on a 64x64 centre window (after a first
+            # call that spins the threads up), then size the crop so that the six renders take ~cpu-seconds together
             c0 = W // 2
             S.render(fs, P, W, H, window=(c0 - 8, c0 - 8, c0 + 8, c0 + 8), nthreads=cores)
             t = time.perf_counter()
             _, _, st_c = S.render(fs, P, W, H, window=(c0 - 32, c0 - 32, c0 + 32, c0 + 32), nthreads=cores)
             t_cal = max(time.perf_counter() - t, 1e-4)
-            side = int(min(W, max(64, 64 * (args.cpu_seconds / t_cal) ** 0.5))) // 16 * 16
+            side = int(min(W, max(64, 64 * (args.cpu_seconds / 6.0 / t_cal) ** 0.5))) // 16 * 16
             x0 = (W - side) // 2
-            t = time.perf_counter()
-            rgba_c, acc_c, st_c = S.render(fs, P, W, H, window=(x0, x0, x0 + side, x0 + side), nthreads=cores)
-            t_cpu = time.perf_counter() - t
+            rgba_c, acc_c, st_c = S.render(fs, P, W, H, window=(x0, x0, x0 + side, x0 + side), nthreads=cores)   # warm-up
+            t_runs = []
+            for _ in range(5):
+                t = time.perf_counter()
+                S.render(fs, P, W, H, window=(x0, x0, x0 + side, x0 + side), nthreads=cores)
+                t_runs.append(time.perf_counter() - t)
+            t_cpu = float(np.mean(t_runs))
             # scale by samples (the crop is denser than the frame average), not by pixels
             frame_s = t_cpu * samples_total / max(1, st_c["samples"])
             out["cpu_baseline"] = {"value": 1.0 / frame_s, "unit": "frames/s", "cores": cores, "kind": "port",
-                                   "sample": f"{side}x{side} centre crop of the same frame ({st_c['samples']} samples, "
-                                             f"{t_cpu:.1f}s on {cores} threads), scaled to the frame by sample count; "
-                                             f"oracle scene build {oracle_box['build_s']:.0f}s not included",
+                                   "sample": f"{side}x{side} centre crop of the same frame ({st_c['samples']} samples; mean of 5 renders "
+                                             f"after 1 warm-up, {t_cpu:.2f}s each on {cores} threads, min {min(t_runs):.2f} max {max(t_runs):.2f}), "
+                                             f"scaled to the frame by sample count; oracle scene build {oracle_box['build_s']:.0f}s not included",
                                    "msamples_per_s": st_c["samples"] / 1e6 / t_cpu}
             # the crop doubles as a full-size parity check of the GPU frame
             img = shards[0].cpu().numpy().view(np.uint32).reshape(H, W)
@@ -608,13 +657,65 @@ def main():
                 "value": 1.0 / (t_1 * samples_total / max(1, st_1["samples"])), "unit": "frames/s", "cores": 1,
                 "msamples_per_s": st_1["samples"] / 1e6 / t_1,
                 "sample": f"{side1}x{side1} centre crop ({st_1['samples']} samples, {t_1:.1f}s on 1 thread), scaled by sample count"}
-        print(json.dumps(out), flush=True)
 
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     for Rk in Rs:
         Rk.close()
+
+    if rank == 0:
+        roof = out["roofline"]
+        if out.pop("_pmc_child", False):
+            # live counters of this very workload, after this process has left the process group and freed its scene
+            # copies: fresh children of rank 0 (program after `--` = the python executable) render what THIS rank rendered
+            # (its shard of the frame for a multi-GPU job) under rocprofv3 --pmc, counters only
+            child = ["--config", args.config, "--scale", str(args.scale), "--size", str(W), "--steps", "2", "--warmup", "1",
+                     "--tile-order", str(args.tile_order), "--accel", str(args.accel), "--cpu-baseline", "off", "--pmc", "off",
+                     "--in-flight", str(F), "--spp", str(args.spp), "--camera", args.camera]
+            child += ["--no-grad"] if args.no_grad else []
+            child += ["--fields", str(args.fields)] if args.fields is not None else []
+            child += ["--iso", str(args.iso)] if args.iso is not None else []
+            child += ["--ao"] if args.ao else []
+            for kv in args.option:
+                child += ["--option", kv]
+            extra = {"EXA_BENCH_SHARD": f"{shard_rank},{shard_world}"} if shard_world > 1 else {}
+            t = time.perf_counter()
+            vals, n = live_pmc(child, extra_env=extra)
+            shard_note = " (the shard of this rank)" if shard_world > 1 else ""
+            if vals:
+                fetch = sum(d.get("FETCH_SIZE", 0.0) for d in vals.values())
+                write = sum(d.get("WRITE_SIZE", 0.0) for d in vals.values())
+                # gfx950 counts a 128-B read request as 64 B in FETCH_SIZE (MI355X_MICROARCH.md): 2 * FETCH_SIZE is the upper bound
+                traffic = (2.0 * fetch + write) * 1024.0
+                vi = sum(d.get("SQ_INSTS_VALU", 0.0) for d in vals.values())
+                roof["pmc_source"] = (f"live: rocprofv3 --pmc passes {[' '.join(c) for c in PMC_PASSES]} run by this bench.py on the same "
+                                      f"workload{shard_note} ({n} frames averaged, "
+                                      f"{time.perf_counter() - t:.0f}s); traffic = 2*FETCH_SIZE({fetch:.6g} KiB) + WRITE_SIZE({write:.6g} KiB)")
+                if len(vals) > 1:
+                    roof["per_kernel"] = {cls: {"valu_wave_instructions": d.get("SQ_INSTS_VALU"),
+                                                "hbm_bytes": (2.0 * d.get("FETCH_SIZE", 0.0) + d.get("WRITE_SIZE", 0.0)) * 1024.0}
+                                          for cls, d in vals.items()}
+            else:
+                log(f"live PMC pass not available ({n})")
+                roof["pmc_live_error"] = str(n)
+                if os.path.exists(traffic_file) and stock:
+                    tf = json.load(open(traffic_file))
+                    traffic, vi = tf.get(key), tf.get(key + ":valu_wave_instructions")
+                    roof["pmc_source"] = tf.get(key + ":note")
+        k_s = roof["kernel_ms"] * 1e-3
+        roof["traffic"] = traffic
+        if traffic:
+            gbs = traffic / k_s / 1e9
+            roof["hbm_measured"] = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+            roof["requested_over_fetched"] = roof["requested_bytes"] / traffic
+        if vi:
+            roof["achieved"] = vi / k_s / 1e9
+            roof["frac"] = roof["achieved"] / VALU_PEAK_GINSTR
+            roof["valu_wave_instructions_per_launch"] = vi
+        else:
+            roof["note"] = "no counters for this configuration: achieved / frac are not reported rather than estimated"
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

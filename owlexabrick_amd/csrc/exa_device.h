@@ -6,6 +6,36 @@
 
 #include <vector>
 
+// ---- build-time switches shared by the module and the kernels (one default for both translation units: the
+//      host writes the march headers the kernel interprets) ----
+#ifndef EXA_OPT_POP1
+#define EXA_OPT_POP1 1
+#endif
+#ifndef EXA_OPT_ADDR32
+#define EXA_OPT_ADDR32 1
+#endif
+#ifndef EXA_OPT_MUL24
+#define EXA_OPT_MUL24 1
+#endif
+#ifndef EXA_OPT_FHDR
+#define EXA_OPT_FHDR 1
+#endif
+#ifndef EXA_OPT_DTPOW2
+#define EXA_OPT_DTPOW2 1
+#endif
+#ifndef EXA_MARCH_WAVES
+#define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup)
+#endif
+#ifndef EXA_MULTI_WAVES
+#define EXA_MULTI_WAVES 6      // ... and the multi-channel march (80 VGPRs; two TF tables + a 3-entry stack: 25 KB of LDS per workgroup)
+#endif
+#ifndef EXA_PREPASS_WAVES
+#define EXA_PREPASS_WAVES 4    // waves per SIMD the surfaces pre-pass is compiled for: 2/3/4/5/6 -> 20.2/15.1/12.6/12.6/16.9 ms on C5
+#endif
+#ifndef EXA_OPT_MED3
+#define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
+#endif
+
 namespace exa {
 
 // One LBVH node = 64 bytes = four 16-byte loads.  Both children's boxes live in

@@ -18,34 +18,6 @@
 //           of the cell index is done on the float
 //   DTPOW2  first sample of a segment: x / dt as x * (1/dt) when dt is a power of two (exact)
 //   MED3    clamp(l, 0, size-1) as one v_med3_i32
-#ifndef EXA_OPT_POP1
-#define EXA_OPT_POP1 1
-#endif
-#ifndef EXA_OPT_ADDR32
-#define EXA_OPT_ADDR32 1
-#endif
-#ifndef EXA_OPT_MUL24
-#define EXA_OPT_MUL24 1
-#endif
-#ifndef EXA_OPT_FHDR
-#define EXA_OPT_FHDR 1
-#endif
-#ifndef EXA_OPT_DTPOW2
-#define EXA_OPT_DTPOW2 1
-#endif
-#ifndef EXA_MARCH_WAVES
-#define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup)
-#endif
-#ifndef EXA_MULTI_WAVES
-#define EXA_MULTI_WAVES 6      // ... and the multi-channel march (80 VGPRs; two TF tables + a 3-entry stack: 25 KB of LDS per workgroup)
-#endif
-#ifndef EXA_PREPASS_WAVES
-#define EXA_PREPASS_WAVES 4    // waves per SIMD the surfaces pre-pass is compiled for: 2/3/4/5/6 -> 20.2/15.1/12.6/12.6/16.9 ms on C5
-#endif
-#ifndef EXA_OPT_MED3
-#define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
-#endif
-
 namespace exa {
 
 // ------------------------------------------------------------------------

@@ -847,9 +847,6 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
     // march headers along the leaf list (the kd march reads the record at listBegin + child, no id indirection).
     // EXA_OPT_FHDR: what a brick visit needs, ready to use — float(lower) (the conversion the reference's
     // `vec3f(brick.lower)` performs, exabrick.cu:623), 2^-level, the sizes and the first cell's offset
-#ifndef EXA_OPT_FHDR
-#define EXA_OPT_FHDR 1
-#endif
     std::vector<ExaBrick> hdr(scene->leafListSize);
     for (uint64_t i = 0; i < scene->leafListSize; i++) {
       const ExaBrick &B = scene->bricks[scene->leafList[i]];
@@ -888,8 +885,14 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
       h->fail("exa_hip_create: region leaf list out of range"); return bail();
     }
     // finestLevelCellWidth = 2^(min level) (exa/Regions.cpp:293-299): the kernels rely on an integer-valued width >= 1
-    if (!(R.finestLevelCellWidth >= 1.f && R.finestLevelCellWidth <= 1073741824.f) || R.finestLevelCellWidth != std::floor(R.finestLevelCellWidth)) {
-      h->fail("exa_hip_create: region finestLevelCellWidth is not an integer >= 1"); return bail();
+    // and on a power of two (the reference only ever writes 1 << finestLevel): the march forms 1/(dt*width) from the
+    // width's exponent bits
+    {
+      int ex = 0;
+      const float mant = std::frexp(R.finestLevelCellWidth, &ex);
+      if (!(R.finestLevelCellWidth >= 1.f && R.finestLevelCellWidth <= 1073741824.f) || mant != 0.5f) {
+        h->fail("exa_hip_create: region finestLevelCellWidth is not a power of two >= 1"); return bail();
+      }
     }
     ri[r].listBegin = R.leafListBegin;
     ri[r].listSize = R.leafListSize;

@@ -3,6 +3,7 @@
 // renderer, N frames instead of a GLUT loop, result written as binary PPM.
 //   exaRender cfg.exa [--size W H] [--camera px py pz  ix iy iz  ux uy uz] [--fov deg]
 //             [--dt f] [--xf file.xf] [--xf-scale s] [--range lo hi] [--isovals a b] [--isochans a b]
+//             [--contourplane nx ny nz offset]... [--contourchan c]...   (exa/viewer.cpp:1199-1207, at most 3 planes)
 //             [--clip-box lx ly lz ux uy uz] [--ao] [--ao-length l] [--no-pg] [--no-space-skipping]
 //             [--gradientShadingDVR 0|1] [--gradientShadingISO 0|1] [--frames N] [-o out.ppm] [--info] [--stats]
 //             [--gpus N | --devices 0,1,..]  one renderer over several GPUs (tiles dealt round-robin, stored straight into
@@ -58,6 +59,8 @@ int main(int argc, char **argv)
     int frames = 1;
     std::vector<int> devices;
     bool pipeline = false;
+    std::vector<float> contourPlanes;                             // 4 floats per --contourplane (normal, offset)
+    std::vector<int> contourChans;
     for (int i = 1; i < argc; i++) {
       const std::string a = argv[i];
       auto f = [&]() { if (i + 1 >= argc) throw std::runtime_error("missing value after " + a); return (float)atof(argv[++i]); };
@@ -70,6 +73,8 @@ int main(int argc, char **argv)
       else if (a == "--range") { range[0] = f(); range[1] = f(); haveRange = true; }
       else if (a == "--isovals") { isoVals[0] = f(); isoVals[1] = f(); isoOn[0] = isoOn[1] = 1; }
       else if (a == "--isochans") { isoChans[0] = (int)f(); isoChans[1] = (int)f(); }
+      else if (a == "--contourplane") { for (int k = 0; k < 4; k++) contourPlanes.push_back(f()); }   // viewer.cpp:1199-1205
+      else if (a == "--contourchan") contourChans.push_back((int)f());                                // viewer.cpp:1206-1207
       else if (a == "--clip-box") { clipBox.lower = { f(), f(), f() }; clipBox.upper = { f(), f(), f() }; clip = true; }
       else if (a == "--ao") ao = true;
       else if (a == "--ao-length") aoLength = f();
@@ -85,7 +90,15 @@ int main(int argc, char **argv)
       else if (a == "--devices") {
         if (i + 1 >= argc) throw std::runtime_error("missing list after --devices");
         devices.clear();
-        for (const char *p = argv[++i]; *p;) { devices.push_back((int)strtol(p, const_cast<char **>(&p), 10)); if (*p == ',') p++; }
+        for (const char *p = argv[++i]; *p;) {
+          char *end = nullptr;
+          const long d = strtol(p, &end, 10);
+          if (end == p || d < 0 || d > 1023 || (*end != ',' && *end != 0)) throw std::runtime_error("--devices wants a comma-separated list of device indices");
+          devices.push_back((int)d);
+          p = *end == ',' ? end + 1 : end;
+          if (*end == ',' && !*p) throw std::runtime_error("--devices wants a comma-separated list of device indices");
+        }
+        if (devices.empty()) throw std::runtime_error("--devices wants a comma-separated list of device indices");
       }
       else if (a == "--pipeline") pipeline = true;
       else if (a[0] != '-') cfgName = a;
@@ -127,6 +140,23 @@ int main(int argc, char **argv)
       renderer.updateXF((int)c, alpha.data(), color, dom, xfScale);
     }
     renderer.updateIsoValues(isoVals, isoChans, isoOn);
+    if (!contourPlanes.empty()) {
+      // the viewer's contour panel set-up (viewer.cpp:673-690): planes given on the command line are enabled, the
+      // others keep their defaults (axis i % 3, offset .5, off); the channels apply when more than one was given
+      vec3f n[MAX_CONTOUR_PLANES]; float off[MAX_CONTOUR_PLANES]; int ch[MAX_CONTOUR_PLANES], en[MAX_CONTOUR_PLANES];
+      if (contourPlanes.size() / 4 > (size_t)MAX_CONTOUR_PLANES) throw std::runtime_error("too many contour planes");
+      for (int i = 0; i < MAX_CONTOUR_PLANES; i++) {
+        if (contourPlanes.size() / 4 > (size_t)i) {
+          n[i] = vec3f(contourPlanes[4 * i], contourPlanes[4 * i + 1], contourPlanes[4 * i + 2]);
+          off[i] = contourPlanes[4 * i + 3]; en[i] = 1;
+        } else {
+          n[i] = vec3f(i % 3 == 0 ? 1.f : 0.f, i % 3 == 1 ? 1.f : 0.f, i % 3 == 2 ? 1.f : 0.f);
+          off[i] = .5f; en[i] = 0;
+        }
+        ch[i] = (contourChans.size() > 1 && (size_t)i < contourChans.size()) ? contourChans[i] : 0;
+      }
+      renderer.updateContourPlanes(n, off, ch, en);
+    }
     renderer.setSpaceSkipping(skipping);
     renderer.setGradientShadingDVR(gradDVR);
     renderer.setGradientShadingISO(gradISO);

@@ -47,26 +47,31 @@ def test_a_failed_rank_ends_the_job_with_a_non_zero_exit():
     assert time.time() - t0 < 25          # the healthy ranks (sleeping 30 s) were ended, not waited for
 
 
-def test_pmc_means_sums_instances_and_averages_dispatches_of_the_shipped_kernel(tmp_path):
-    """the live PMC leg of bench.py: per dispatch the counter instances are summed, dispatches of the shipped march
-    kernel (STATS template argument 0) are averaged, the instrumented variant and other kernels are left out"""
+def test_pmc_frame_totals_sum_the_kernels_of_a_frame(tmp_path):
+    """the live PMC leg of bench.py: per dispatch the counter instances are summed; a frame is one dispatch of the shipped
+    march kernel (STATS template argument 0); the wide-march and surfaces pre-pass dispatches are the same frames' work
+    and are reported per frame by class; the instrumented variant and other kernels are left out"""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    MARCH_RE = bench.MARCH_KERNEL_RE
     shipped = "void exa::renderFrameKdKernel<true, true, 0, false, 0, true>(exa::RenderArgs)"
     counted = "void exa::renderFrameKdKernel<true, true, 0, false, 1, false>(exa::RenderArgs)"
+    wide = "void exa::renderFrameKdWideKernel<true, true, false, 4, true>(exa::RenderArgs)"
+    pre = "void exa::surfacePrepassKdKernel<0>(exa::RenderArgs)"
     rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value"]
     rows += [f'1,1,0,"{counted}",FETCH_SIZE,1000.0']
     rows += [f'2,2,0,"{shipped}",FETCH_SIZE,10.0', f'2,2,0,"{shipped}",FETCH_SIZE,30.0']       # two instances
     rows += [f'3,3,0,"{shipped}",FETCH_SIZE,60.0', f'3,3,0,"{shipped}",WRITE_SIZE,5.0']
+    rows += [f'5,5,0,"{wide}",FETCH_SIZE,8.0', f'6,6,0,"{pre}",FETCH_SIZE,4.0', f'7,7,0,"{pre}",FETCH_SIZE,2.0']
     rows += ['4,4,0,"void exa::untileKernel(unsigned int*)",FETCH_SIZE,7.0']
     f = tmp_path / "1_counter_collection.csv"
     f.write_text("\n".join(rows) + "\n")
-    means, n = bench.pmc_means([str(f)], MARCH_RE)
-    assert means == {"FETCH_SIZE": 50.0, "WRITE_SIZE": 5.0} and n == 2
-    lbvh = "void exa::renderFrameKernel<true, true, false, 0>(exa::RenderArgs)"
+    tot, frames = bench.pmc_frame_totals([str(f)])
+    assert frames == 2
+    assert tot == {"march": {"FETCH_SIZE": 50.0, "WRITE_SIZE": 2.5}, "march_wide": {"FETCH_SIZE": 4.0},
+                   "surfaces_prepass": {"FETCH_SIZE": 3.0}}
+    lbvh = "void exa::renderFrameKernel<true, true, 0>(exa::RenderArgs)"
     f.write_text(rows[0] + f'\n1,1,0,"{lbvh}",SQ_INSTS_VALU,3.0\n')
-    assert bench.pmc_means([str(f)], MARCH_RE) == ({"SQ_INSTS_VALU": 3.0}, 1)
-    assert bench.pmc_means([], MARCH_RE) == ({}, 0)
+    assert bench.pmc_frame_totals([str(f)]) == ({"march": {"SQ_INSTS_VALU": 3.0}}, 1)
+    assert bench.pmc_frame_totals([]) == ({}, 0)

@@ -58,6 +58,15 @@ def test_random_case_with_three_or_four_fields_matches_oracle(seed):
     assert not bad, (desc, bad)
 
 
+# 803: a ray whose opacity crosses 0.98 within an ulp of powf on two pixels of one small frame (the reason the flip
+# allowance of tests/common.py is "at least 2 pixels per frame")
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 803])
+def test_random_case_with_odd_tf_domains_matches_oracle(seed):
+    """degenerate, reversed, very narrow, far too wide TF domains"""
+    bad, desc = check(seed, rich="domains")
+    assert not bad, (desc, bad)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_deep_scene_matches_oracle(seed):
     """generated scenes of 1e5..2e6 cells: deep kd trees (short-stack restarts), packed leaf references, long rays"""

@@ -426,6 +426,21 @@ def test_errors_are_reported_not_swallowed():
     R.close()
 
 
+def test_region_cell_width_must_be_a_power_of_two():
+    """the reference only writes finestLevelCellWidth = 1 << finestLevel (exa/Regions.cpp:293-299) and the march forms
+    1/(dt*width) from the width's exponent bits: a hand-built scene with any other width is refused, not mis-sampled"""
+    from owlexabrick_amd import binding
+    prep = binding.Prep(scenes.example("ex3"))
+    regs = prep.regions()
+    keep = regs["finestLevelCellWidth"][0]
+    for bad in (3.0, 0.5, 6.0, float("nan")):
+        regs["finestLevelCellWidth"][0] = bad
+        with pytest.raises(RuntimeError, match="power of two"):
+            binding.Renderer(prep)
+    regs["finestLevelCellWidth"][0] = keep
+    binding.Renderer(prep).close()
+
+
 def test_full_frame_properties_at_benchmark_size():
     """2048x2048 on an exajet-like scene: properties that do not need the oracle at full size,
     plus an oracle check on a crop."""
