@@ -147,7 +147,7 @@ def live_pmc(child_args, seconds=300.0, extra_env=None):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     out_dir = tempfile.mkdtemp(prefix="exa_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", EXA_BENCH_CPU_THREADS="2")
+    env = dict(os.environ, TMPDIR="/tmp", EXA_BENCH_CPU_THREADS="2", EXA_BENCH_NO_LATENCY="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
               "EXA_BENCH_FORCE_DIST", "EXA_BENCH_SHARD", "EXA_BENCH_SPAWNED", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
@@ -484,7 +484,7 @@ def main():
     #      loop would see.  With one frame in flight the timed region above already is that; with several, measure it
     #      here with the critical tiles marched wide (wide_march = 1, the lone-frame default) ----
     latency_ms = None
-    if F > 1:
+    if F > 1 and not os.environ.get("EXA_BENCH_NO_LATENCY"):      # (the PMC children below only need the timed region's frames)
         R.setOption("wide_march", 1)
         cur = torch.cuda.current_stream().cuda_stream
         for _ in range(3):                          # layout changed: cost feedback measures, re-orders, assigns wide tiles

@@ -251,7 +251,11 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * 1 = region kd-tree walked front to back (default when the scene carries one); "lbvh_build" 0 (default) = that LBVH
  * is built on the device (Morton codes, radix sort, topology level by level), 1 = the same tree built on the host;
  * "fast_sampler" 1 (default) = the surfaces pre-pass of the kd path samples through the march headers with the
- * masked-weight basis evaluation, 0 = with the literal addBasisFunctions (same sums bit for bit); "tile_feedback" 1 (default) = after a
+ * masked-weight basis evaluation, 0 = with the literal addBasisFunctions (same sums bit for bit); "interleave" 1 (default) =
+ * a DVR march of 2..4 primary channels reads a channel-interleaved copy float[cell][channel] of those fields (built on
+ * the device at the first such frame) and evaluates all channels per brick visit, 0 = field by field from the arrays
+ * as uploaded; "addr64" 1 = the march forms 64-bit cell / header / node addresses even where a scene is small enough for
+ * 32-bit offsets from a uniform base (default 0: chosen per scene; tests); "tile_feedback" 1 (default) = after a
  * change of view / TF / layout the next synchronous frame records every tile's longest ray and later frames launch
  * the heaviest tiles first (a frame's critical path is its longest rays), 0 = keep the static order; "wide_march" 1
  * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes

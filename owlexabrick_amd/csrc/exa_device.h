@@ -32,6 +32,12 @@
 #ifndef EXA_PREPASS_WAVES
 #define EXA_PREPASS_WAVES 4    // waves per SIMD the surfaces pre-pass is compiled for: 2/3/4/5/6 -> 20.2/15.1/12.6/12.6/16.9 ms on C5
 #endif
+#ifndef EXA_IL2_WAVES
+#define EXA_IL2_WAVES 5        // waves per SIMD of the channel-interleaved march with two channels ...
+#endif
+#ifndef EXA_IL34_WAVES
+#define EXA_IL34_WAVES 4       // ... and with three or four (their cell values and sums need the registers)
+#endif
 #ifndef EXA_OPT_MED3
 #define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
 #endif
@@ -144,6 +150,9 @@ struct RenderArgs {
   ExaHipFrameState   fs;
   ExaHipParams       p;
   const float4      *xf;            // numXfChannels x 128 (r,g,b,a)
+  const float       *cellsIl;       // channel-interleaved copy of the primary channels, float[cell][numPrimaryChannels]
+                                    // (NULL: none; the march then reads the fields one after the other)
+  int32_t            il32;          // ... and it is below 4 GiB (32-bit byte offsets)
   int32_t            mul24;         // every brick: sizes < 2^24, size.x*size.y < 2^24, cells < 2^32 -> 24-bit multiplies
   int32_t            addr32;        // a scalar field, the march headers and the kd nodes are each below 4 GiB ->
                                     // 32-bit byte offsets from a uniform base
@@ -187,6 +196,8 @@ hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay
 hipError_t launchKdRefit(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
 // computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel
 hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s);
+// out[cell * nch + c] = scalars[channelOffset[c] + cell] for c < nch
+hipError_t launchInterleave(const DeviceScene &sc, unsigned long long totalCells, int nch, float *out, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,
                         int W, int H, uint32_t *out, hipStream_t s);
 

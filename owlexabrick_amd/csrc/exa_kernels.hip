@@ -465,6 +465,121 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   }
 }
 
+// Channel-interleaved form of addBasisFast for the multi-channel DVR march: the NCH primary channels of a cell lie side
+// by side (float[cell][NCH], built by the module from the field-major arrays of the ABI), so the two x-neighbours of a row
+// are 2*NCH adjacent floats — one load per row for ALL channels where the field-major layout takes one per row and
+// channel, from arrays gigabytes apart.  The cell indices, the six masked weights and the sums that do not depend on the
+// cell values (sumW, sumDC) are the same for every channel (same position, same brick) and are evaluated once; per
+// channel only sumWV / sumD remain (8 instead of 13 instructions per corner, none of the ~90 of the index arithmetic).
+// Each channel's sums see exactly the additions, in exactly the order, of addBasisFast on that channel's field: the
+// reference's per-channel samplePoint calls (exabrick.cu:1163-1178) are independent of each other, so evaluating them
+// side by side changes no value.  xWV / xD: the sums of channels 1..NCH-1 (channel 0 lives in B).
+template <int NCH> struct __attribute__((packed, aligned(4))) PairN { float v[2 * NCH]; };
+
+template <bool DERIV, bool SMALL, int NCH>
+__device__ __forceinline__ void addBasisFastIl(Basis &B, float *xWV, V3 *xD, const int4 b0, const int4 b1,
+                                               const float *__restrict__ cellsIl, V3 pos)
+{
+  static_assert(EXA_OPT_FHDR, "the interleaved march reads the float march headers");
+  const int sx = b1.x, sy = b1.y, sz = b1.z;
+  const uint32_t begin = (uint32_t)b1.w;
+  const float invCw = __int_as_float(b0.w);
+  const float lpx = (pos.x - __int_as_float(b0.x)) * invCw - 0.5f;
+  const float lpy = (pos.y - __int_as_float(b0.y)) * invCw - 0.5f;
+  const float lpz = (pos.z - __int_as_float(b0.z)) * invCw - 0.5f;
+  const float flx = fmaxf(floorf(lpx), -1.f), fly = fmaxf(floorf(lpy), -1.f), flz = fmaxf(floorf(lpz), -1.f);
+  const int lx = int(flx), ly = int(fly), lz = int(flz);
+  const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
+  const float fx = lpx - flx, fy = lpy - fly, fz = lpz - flz;
+  const bool vlx = (uint32_t)lx < (uint32_t)sx, vhx = hx < sx;
+  const bool vly = (uint32_t)ly < (uint32_t)sy, vhy = hy < sy;
+  const bool vlz = (uint32_t)lz < (uint32_t)sz, vhz = hz < sz;
+  auto med3 = [](int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+  const int cxl = med3(lx, 0, sx - 1), cxh = min(hx, sx - 1);
+  const int cyl = med3(ly, 0, sy - 1), cyh = min(hy, sy - 1);
+  const int czl = med3(lz, 0, sz - 1), czh = min(hz, sz - 1);
+  const int bx = med3(lx, 0, max(sx - 2, 0));
+  uint32_t rowLL, rowHL, rowLH, rowHH;                      // cell index of the pair's first cell, per (y,z) row
+  if (EXA_OPT_MUL24 && SMALL) {
+    const uint32_t sxy = __umul24((uint32_t)sx, (uint32_t)sy);
+    const uint32_t zl = __umul24((uint32_t)czl, sxy) + (begin + (uint32_t)bx);
+    const uint32_t zh = __umul24((uint32_t)czh, sxy) + (begin + (uint32_t)bx);
+    const uint32_t yl = __umul24((uint32_t)cyl, (uint32_t)sx), yh = __umul24((uint32_t)cyh, (uint32_t)sx);
+    rowLL = zl + yl; rowHL = zl + yh; rowLH = zh + yl; rowHH = zh + yh;
+  } else {
+    const uint32_t sxy = (uint32_t)(sx * sy);
+    const uint32_t zl = begin + (uint32_t)czl * sxy + (uint32_t)bx, zh = begin + (uint32_t)czh * sxy + (uint32_t)bx;
+    const uint32_t yl = (uint32_t)(cyl * sx), yh = (uint32_t)(cyh * sx);
+    rowLL = zl + yl; rowHL = zl + yh; rowLH = zh + yl; rowHH = zh + yh;
+  }
+  const bool lFirst = cxl == bx, hFirst = cxh == bx;
+  PairN<NCH> pLL, pHL, pLH, pHH;
+  if (SMALL) {
+    // SMALL: the interleaved array is below 4 GiB: wave-uniform base + 32-bit byte offset per lane
+    const char *base = reinterpret_cast<const char *>(cellsIl);
+    pLL = *reinterpret_cast<const PairN<NCH> *>(base + rowLL * (uint32_t)(4 * NCH)); pHL = *reinterpret_cast<const PairN<NCH> *>(base + rowHL * (uint32_t)(4 * NCH));
+    pLH = *reinterpret_cast<const PairN<NCH> *>(base + rowLH * (uint32_t)(4 * NCH)); pHH = *reinterpret_cast<const PairN<NCH> *>(base + rowHH * (uint32_t)(4 * NCH));
+  } else {
+    pLL = *reinterpret_cast<const PairN<NCH> *>(cellsIl + size_t(rowLL) * NCH); pHL = *reinterpret_cast<const PairN<NCH> *>(cellsIl + size_t(rowHL) * NCH);
+    pLH = *reinterpret_cast<const PairN<NCH> *>(cellsIl + size_t(rowLH) * NCH); pHH = *reinterpret_cast<const PairN<NCH> *>(cellsIl + size_t(rowHH) * NCH);
+  }
+  const float wxl = vlx ? 1.f - fx : 0.f, wxh = vhx ? fx : 0.f;
+  const float wyl = vly ? 1.f - fy : 0.f, wyh = vhy ? fy : 0.f;
+  const float wzl = vlz ? 1.f - fz : 0.f, wzh = vhz ? fz : 0.f;
+  const float zyLL = wzl * wyl, zyLH = wzl * wyh, zyHL = wzh * wyl, zyHH = wzh * wyh;
+  // the eight trilinear weights, in the reference's association (z*y)*x
+  const float w000 = zyLL * wxl, w100 = zyLL * wxh, w010 = zyLH * wxl, w110 = zyLH * wxh;
+  const float w001 = zyHL * wxl, w101 = zyHL * wxh, w011 = zyHH * wxl, w111 = zyHH * wxh;
+  B.sumW += w000; B.sumW += w100; B.sumW += w010; B.sumW += w110;
+  B.sumW += w001; B.sumW += w101; B.sumW += w011; B.sumW += w111;
+  float mxl = 0.f, mxh = 0.f, myl = 0.f, myh = 0.f, mzl = 0.f, mzh = 0.f;
+  float zxLL = 0.f, zxLH = 0.f, zxHL = 0.f, zxHH = 0.f, yxLL = 0.f, yxLH = 0.f, yxHL = 0.f, yxHH = 0.f;
+  if (DERIV) {
+    mxl = vlx ? -1.f : 0.f; mxh = vhx ? 1.f : 0.f;
+    myl = vly ? -1.f : 0.f; myh = vhy ? 1.f : 0.f;
+    mzl = vlz ? -1.f : 0.f; mzh = vhz ? 1.f : 0.f;
+    zxLL = wzl * wxl; zxLH = wzl * wxh; zxHL = wzh * wxl; zxHH = wzh * wxh;   // [z][x]
+    yxLL = wyl * wxl; yxLH = wyl * wxh; yxHL = wyh * wxl; yxHH = wyh * wxh;   // [y][x]
+    // sumDC += (+-)(product of the other two axes' weights): exact-product fma, as in addBasisFast
+#define EXA_DC(ZY, MX, ZX, MY, YX, MZ)                                                       \
+    B.sumDC.x = __builtin_fmaf((ZY), (MX), B.sumDC.x);                                       \
+    B.sumDC.y = __builtin_fmaf((ZX), (MY), B.sumDC.y);                                       \
+    B.sumDC.z = __builtin_fmaf((YX), (MZ), B.sumDC.z);
+    EXA_DC(zyLL, mxl, zxLL, myl, yxLL, mzl) EXA_DC(zyLL, mxh, zxLH, myl, yxLH, mzl)
+    EXA_DC(zyLH, mxl, zxLL, myh, yxHL, mzl) EXA_DC(zyLH, mxh, zxLH, myh, yxHH, mzl)
+    EXA_DC(zyHL, mxl, zxHL, myl, yxLL, mzh) EXA_DC(zyHL, mxh, zxHH, myl, yxLH, mzh)
+    EXA_DC(zyHH, mxl, zxHL, myh, yxHL, mzh) EXA_DC(zyHH, mxh, zxHH, myh, yxHH, mzh)
+#undef EXA_DC
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; c++) {
+    float &sumWV = c == 0 ? B.sumWV : xWV[c == 0 ? 0 : c - 1];
+    V3 &sumD = c == 0 ? B.sumD : xD[c == 0 ? 0 : c - 1];
+    const float s000 = lFirst ? pLL.v[c] : pLL.v[NCH + c], s100 = hFirst ? pLL.v[c] : pLL.v[NCH + c];
+    const float s010 = lFirst ? pHL.v[c] : pHL.v[NCH + c], s110 = hFirst ? pHL.v[c] : pHL.v[NCH + c];
+    const float s001 = lFirst ? pLH.v[c] : pLH.v[NCH + c], s101 = hFirst ? pLH.v[c] : pLH.v[NCH + c];
+    const float s011 = lFirst ? pHH.v[c] : pHH.v[NCH + c], s111 = hFirst ? pHH.v[c] : pHH.v[NCH + c];
+#define EXA_ACC(S, W, ZY, MX, ZX, MY, YX, MZ)                                                \
+    {                                                                                        \
+      if (DERIV) {                                                                           \
+        sumD.x = __builtin_fmaf((ZY) * (S), (MX), sumD.x);                                   \
+        sumD.y = __builtin_fmaf((ZX) * (S), (MY), sumD.y);                                   \
+        sumD.z = __builtin_fmaf((YX) * (S), (MZ), sumD.z);                                   \
+      }                                                                                      \
+      sumWV += (W) * (S);                                                                    \
+    }
+    EXA_ACC(s000, w000, zyLL, mxl, zxLL, myl, yxLL, mzl)
+    EXA_ACC(s100, w100, zyLL, mxh, zxLH, myl, yxLH, mzl)
+    EXA_ACC(s010, w010, zyLH, mxl, zxLL, myh, yxHL, mzl)
+    EXA_ACC(s110, w110, zyLH, mxh, zxLH, myh, yxHH, mzl)
+    EXA_ACC(s001, w001, zyHL, mxl, zxHL, myl, yxLL, mzh)
+    EXA_ACC(s101, w101, zyHL, mxh, zxHH, myl, yxLH, mzh)
+    EXA_ACC(s011, w011, zyHH, mxl, zxHL, myh, yxHL, mzh)
+    EXA_ACC(s111, w111, zyHH, mxh, zxHH, myh, yxHH, mzh)
+#undef EXA_ACC
+  }
+}
+
 // exabrick.cu:781-806 samplePoint / :883-928 samplePointWithDerivative
 template <bool DERIV, int STATS>
 __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &derivatives,
@@ -1574,9 +1689,12 @@ __global__ __launch_bounds__(kKdBlock, EXA_PREPASS_WAVES) void surfacePrepassKdK
 }
 
 // MULTI: 0 = one primary channel; 1 = several, at most two TF tables in LDS (the 6-workgroup layout below); 2 = several, more tables
-template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL>
-__global__ __launch_bounds__(kKdBlock, (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 5 : EXA_MARCH_WAVES))) void renderFrameKdKernel(const RenderArgs a)
+// NCH: 0 = cell values field by field (the ABI's layout; one channel, or the channels one after the other);
+//      2..4 = that many primary channels from the channel-interleaved copy, all of them per brick visit (addBasisFastIl)
+template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL, int NCH = 0>
+__global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL34_WAVES) : (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 5 : EXA_MARCH_WAVES)))) void renderFrameKdKernel(const RenderArgs a)
 {
+  static_assert(NCH == 0 || (MULTI == 2 && STATS == 0), "the interleaved march is a multi-channel variant of the shipped kernel");
   // Entries of the lane's short stack.  The two-table multi-channel march runs with one fewer: a workgroup then needs
   // 25 KB instead of 28 KB of LDS and a sixth workgroup fits a CU (C3: 30.8 -> 29.4 ms; a shorter stack alone costs ~1 %:
   // a dropped entry is re-found by a restart from the root).  With three tables the sixth workgroup does not fit either
@@ -1680,6 +1798,11 @@ __global__ __launch_bounds__(kKdBlock, (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 
     int4 hb0 = make_int4(0, 0, 0, 1), hb1 = make_int4(1, 1, 1, 0);
     Basis B;
     B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+    // interleaved march: value-weighted sums of channels 1..NCH-1 (channel 0 and the shared sumW / sumDC live in B)
+    float xWV[NCH > 1 ? NCH - 1 : 1];
+    V3 xD[NCH > 1 ? NCH - 1 : 1];
+#pragma unroll
+    for (int c = 0; c < (NCH > 1 ? NCH - 1 : 1); c++) { xWV[c] = 0.f; xD[c] = mk(0.f, 0.f, 0.f); }
     const float *field0 = a.sc.scalars + a.sc.channelOffset[0];   // wave-uniform
     const float *field = field0;
     // fast_math, one channel: the reciprocal of the TF range is the same for every sample of the frame; it is
@@ -1759,14 +1882,31 @@ __global__ __launch_bounds__(kKdBlock, (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 
         }
         w.pk.set(PK_NEEDHDR, 0);
       }
-      addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
+      if (NCH) addBasisFastIl<GRAD, SMALL, (NCH ? NCH : 2)>(B, xWV, xD, hb0, hb1, a.cellsIl, ray.org + t_sample * ray.dir);
+      else addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
       child++;
       if (child < listSize) continue;
 
       // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
       C.lap(ST_T_FINAL);
       C.phase(ST_W_FINAL);
-      if (B.sumW > 1e-20f) {
+      if (NCH) {
+        // every primary channel's sample of this step, in channel order (:1163-1178); valid or not is the same for all
+        // of them (sumW does not depend on the cell values)
+        if (B.sumW > 1e-20f) {
+#pragma unroll
+          for (int c = 0; c < NCH; c++) {
+            const float wv = c == 0 ? B.sumWV : xWV[c == 0 ? 0 : c - 1];
+            const V3 sd = c == 0 ? B.sumD : xD[c == 0 ? 0 : c - 1];
+            const float cellValue = fdivExact<FAST>(wv, B.sumW);
+            V3 grad = mk(0.f, 0.f, 0.f);
+            if (GRAD) grad = mk(B.sumW * sd.x - wv * B.sumDC.x, B.sumW * sd.y - wv * B.sumDC.y, B.sumW * sd.z - wv * B.sumDC.z);
+            integrateVolume<FAST, STATS, false>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, c, 0.f);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < (NCH > 1 ? NCH - 1 : 1); c++) { xWV[c] = 0.f; xD[c] = mk(0.f, 0.f, 0.f); }
+      } else if (B.sumW > 1e-20f) {
         C.count(ST_SAMPLES);
         const float cellValue = fdivExact<FAST>(B.sumWV, B.sumW);
         V3 grad = mk(0.f, 0.f, 0.f);
@@ -1777,7 +1917,7 @@ __global__ __launch_bounds__(kKdBlock, (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0;
-      if (MULTI) {
+      if (MULTI && !NCH) {
         chan++;
         if (chan < numChannels) {
           field = a.sc.scalars + a.sc.channelOffset[chan];
@@ -2255,8 +2395,10 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
   // 0: one primary channel; 1: several with at most two TF tables (3-entry stack, 6 workgroups per CU); 2: several, more tables.
   // The instrumented variants exist for 0 and 2 only.
   const int mode = a.p.numPrimaryChannels > 1 ? ((a.numXfChannels <= 2 && !stats) ? 1 : 2) : 0;
+  // interleaved march: the module has built float[cell][numPrimaryChannels] (a.cellsIl); shipped kernel only
+  const int nch = (a.cellsIl && !stats && a.p.numPrimaryChannels >= 2 && a.p.numPrimaryChannels <= 4) ? a.p.numPrimaryChannels : 0;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4)
-                   + size_t((mode == 1 ? kKdStackMulti : kKdStack) + kSegQueue) * kKdBlock * 12 + EXA_LDS_PAD;
+                   + size_t((mode == 1 && !nch ? kKdStackMulti : kKdStack) + kSegQueue) * kKdBlock * 12 + EXA_LDS_PAD;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   // the instrumented variants keep the general address arithmetic (fewer instantiations)
   const bool small = a.mul24 && a.addr32;
@@ -2265,6 +2407,21 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
                                    else if (small) EXA_LAUNCH(G, F, M, I, 0, true); else EXA_LAUNCH(G, F, M, I, 0, false); } while (0)
 #define EXA_PICK(G, F, M) do { if (surf) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
 #define EXA_PICKM(G, F) do { if (mode == 0) EXA_PICK(G, F, 0); else if (mode == 1) EXA_PICK(G, F, 1); else EXA_PICK(G, F, 2); } while (0)
+  if (nch) {
+    // LDS: nch TF tables + a 4-entry stack + the queue = 28 / 30 / 32 KB per workgroup (5 workgroups per CU)
+    const bool smallIl = small && a.il32;
+#define EXA_IL4(G, F, I, A, N) hipLaunchKernelGGL((renderFrameKdKernel<G, F, 2, I, 0, A, N>), grid, block, lds, s, a)
+#define EXA_IL3(G, F, I, A) do { if (nch == 2) EXA_IL4(G, F, I, A, 2); else if (nch == 3) EXA_IL4(G, F, I, A, 3); else EXA_IL4(G, F, I, A, 4); } while (0)
+#define EXA_IL2(G, F, I) do { if (smallIl) EXA_IL3(G, F, I, true); else EXA_IL3(G, F, I, false); } while (0)
+#define EXA_IL1(G, F) do { if (surf) EXA_IL2(G, F, true); else EXA_IL2(G, F, false); } while (0)
+    if (grad) { if (fast) EXA_IL1(true, true); else EXA_IL1(true, false); }
+    else      { if (fast) EXA_IL1(false, true); else EXA_IL1(false, false); }
+#undef EXA_IL1
+#undef EXA_IL2
+#undef EXA_IL3
+#undef EXA_IL4
+    return hipGetLastError();
+  }
   if (grad) { if (fast) EXA_PICKM(true, true); else EXA_PICKM(true, false); }
   else      { if (fast) EXA_PICKM(false, true); else EXA_PICKM(false, false); }
 #undef EXA_PICKM
@@ -2470,6 +2627,27 @@ hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const 
 {
   if (count <= 0) return hipSuccess;
   hipLaunchKernelGGL(refitKernel, dim3((count + 255) / 256), dim3(256), 0, s, nodes, nodeIds, count, domain, active);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
+// channel-interleaved copy of the primary channels for the multi-channel march: out[cell][c] = field_c[cell]
+// (exabrick.cu:581-594 reads field c at scalarBuffers[offset[c] + index]; the copy only changes where a value lives)
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void interleaveKernel(DeviceScene sc, unsigned long long totalCells, int nch, float *out)
+{
+  const unsigned long long n = totalCells * (unsigned long long)nch;
+  for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256ull) {
+    const unsigned long long cell = i / (unsigned)nch;
+    const int c = (int)(i - cell * (unsigned)nch);
+    out[i] = sc.scalars[sc.channelOffset[c] + cell];
+  }
+}
+
+hipError_t launchInterleave(const DeviceScene &sc, unsigned long long totalCells, int nch, float *out, hipStream_t s)
+{
+  if (totalCells == 0) return hipSuccess;
+  hipLaunchKernelGGL(interleaveKernel, dim3(256 * 64), dim3(256), 0, s, sc, totalCells, nch, out);
   return hipGetLastError();
 }
 

@@ -212,6 +212,13 @@ struct ExaHipRenderer {
   DevBuf<int32_t> leafList;
   DevBuf<int4> leafHdr;
   DevBuf<float> scalars;
+  // channel-interleaved copy of the primary channels, float[cell][ilChannels], for the multi-channel march (built on the
+  // device by the first frame that marches 2..4 channels; the field-major arrays of the ABI stay for everything else)
+  DevBuf<float> cellsIl;
+  int ilChannels = 0;
+  int interleave = 1;                // option "interleave"
+  int addr64 = 0;                    // option "addr64": the general 64-bit address form even where 32-bit offsets would do (tests)
+  uint64_t totalCells = 0;
   DevBuf<RegionInfo> regionInfo;
   DevBuf<float2> valueRange;
   DevBuf<float> domain;
@@ -604,6 +611,20 @@ struct ExaHipRenderer {
       xfDirty = false;
     }
     if (needLbvh() && ensureLbvh()) return 1;
+    {
+      const int want = (useKd() && interleave && p.numPrimaryChannels >= 2 && p.numPrimaryChannels <= 4) ? p.numPrimaryChannels : 0;
+      if (want != ilChannels) {
+        HIP_TRY(this, hipStreamSynchronize(s));            // frames in flight may still read the old copy
+        cellsIl.release();
+        ilChannels = 0;
+        if (want) {
+          HIP_TRY(this, cellsIl.alloc(size_t(totalCells) * want + 2 * size_t(want)));     // a pair load may reach one cell past the end
+          HIP_TRY(this, hipMemsetAsync(cellsIl.p + size_t(totalCells) * want, 0, 2 * size_t(want) * sizeof(float), s));
+          HIP_TRY(this, launchInterleave(sc, totalCells, want, cellsIl.p, s));
+          ilChannels = want;
+        }
+      }
+    }
     const bool needIso = isoEnabled();
     if (volDirty || (needIso && isoDirty)) {
       HIP_TRY(this, hipEventRecord(ev2, s));
@@ -703,7 +724,9 @@ struct ExaHipRenderer {
     a.xf = xf.p;
     a.tfFracMagic = tfFracMagic();
     a.fastSampler = fastSampler;
-    a.mul24 = mul24; a.addr32 = addr32;
+    a.mul24 = mul24; a.addr32 = addr64 ? 0 : addr32;
+    a.cellsIl = ilChannels == p.numPrimaryChannels ? cellsIl.p : nullptr;
+    a.il32 = (uint64_t(totalCells) + 2) * uint64_t(ilChannels > 0 ? ilChannels : 1) * sizeof(float) <= (1ull << 32) && !addr64 ? 1 : 0;
     {
       // launch.dt a power of two (the reference's default 0.5 is): 1/dt is exact and x/dt == x*(1/dt)
       int e = 0;
@@ -839,6 +862,7 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
     if (scene->channelOffset[f] + scene->totalCells > uint64_t(scene->numFields) * scene->totalCells) { h->fail("exa_hip_create: channel offset out of range"); return bail(); }
 
   h->numFields = scene->numFields;
+  h->totalCells = scene->totalCells;
   for (int k = 0; k < 3; k++) { h->voxLo[k] = scene->voxelBounds_lo[k]; h->voxHi[k] = scene->voxelBounds_hi[k]; }
   static_assert(sizeof(ExaBrick) == 2 * sizeof(int4), "brick = two int4");
   CREATE_TRY(h->bricks.upload(reinterpret_cast<const int4 *>(scene->bricks), scene->numBricks * 2));
@@ -1341,6 +1365,8 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
   if (!std::strcmp(key, "fast_sampler")) { h->fastSampler = value; return 0; }
+  if (!std::strcmp(key, "interleave")) { h->interleave = value != 0; return 0; }
+  if (!std::strcmp(key, "addr64")) { h->addr64 = value != 0; return 0; }
   if (!std::strcmp(key, "tf_filter")) {
     if (value != 0 && value != 1) { h->fail("exa_hip_set_option: tf_filter is 0 or 1"); return 1; }
     if (value != h->tfFilter) { h->tfFilter = value; h->volDirty = true; }     // region activity goes through the TF lookup

@@ -1,0 +1,71 @@
+"""Channel-interleaved cell values for the multi-channel DVR march (option "interleave", default on): the module re-lays
+the primary channels as float[cell][channel] on the device and the march evaluates all channels of a sample per brick
+visit.  Same values, same sums in the same order: the frame must equal the field-by-field march bit for bit, and the
+oracle within the stated tolerance (the seeded families of tests/test_gpu_fuzz.py cover the latter with 2..4 fields)."""
+import numpy as np
+import pytest
+
+from common import Case, band_xf, compare
+from owlexabrick_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(nf, seed=5):
+    return scenes.amr(seed=seed, root=(3, 2, 2), B=4, levels=3, fields=nf)
+
+
+def _run(case, **options):
+    case.options = options
+    return case.run_hip(frames=2)
+
+
+@pytest.mark.parametrize("nf", [2, 3, 4])
+@pytest.mark.parametrize("grad", [0, 1])
+@pytest.mark.parametrize("fast_math", [0, 1])
+def test_interleaved_march_equals_field_by_field_march(nf, grad, fast_math):
+    kw = dict(W=120, H=88, grad=grad, fast_math=fast_math, xf=[band_xf(0.2 + 0.1 * c, 0.9) for c in range(nf)], opacity_scale=0.6)
+    ref = _run(Case(_scene(nf), **kw), interleave=0)
+    for opts in (dict(interleave=1), dict(interleave=1, addr64=1)):
+        got = _run(Case(_scene(nf), **kw), **opts)
+        assert np.array_equal(ref[0], got[0]), opts
+        assert np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32)), opts
+
+
+@pytest.mark.parametrize("nf", [2, 3])
+def test_interleaved_march_with_surfaces_clip_and_shards(nf):
+    """iso-surface pre-pass in front (it samples the field-major arrays), a clip box, and a sharded handle"""
+    from owlexabrick_amd import binding
+    sc = _scene(nf, seed=9)
+    kw = dict(W=96, H=96, grad=1, iso=[(0.45, nf - 1)], clip=None)
+    ref = _run(Case(sc, **kw), interleave=0)
+    got = _run(Case(sc, **kw), interleave=1)
+    assert np.array_equal(ref[1].view(np.uint32), got[1].view(np.uint32))
+    o = Case(sc, **kw, fast_math=0).run_oracle(frames=2)
+    case = Case(sc, **kw, fast_math=0)
+    case.options = dict(interleave=1)
+    h = case.run_hip(frames=2)
+    r = compare(o, h)
+    assert r["flips_ok"] and r["rgba_bad"] <= 3 * r["flip_pixels"] and (r["accum_bad"] == 0 or r["flip_pixels"] > 0), r
+
+
+def test_changing_the_number_of_primary_channels_rebuilds_the_copy():
+    """multiFieldDvr on -> off -> on (numPrimaryChannels 3 -> 1 -> 3) on one handle equals fresh handles"""
+    sc = _scene(3, seed=2)
+    case = Case(sc, W=64, H=64, grad=1)
+    R = case.hip_renderer()
+    a3 = R.render().copy()
+    R.params.numPrimaryChannels = 1
+    a1 = R.render().copy()
+    R.params.numPrimaryChannels = 2
+    a2 = R.render().copy()
+    R.params.numPrimaryChannels = 3
+    assert np.array_equal(R.render(), a3)
+    R.close()
+    for n, want in ((1, a1), (2, a2)):
+        c2 = Case(sc, W=64, H=64, grad=1)
+        c2.options = dict(interleave=0)
+        R2 = c2.hip_renderer()
+        R2.params.numPrimaryChannels = n
+        assert np.array_equal(R2.render(), want), n
+        R2.close()
