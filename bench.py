@@ -104,7 +104,8 @@ def spawn_ranks(n):
 
 # the kernels of one frame: the shipped march (STATS template argument 0), its wide variants for critical tiles, and the
 # surfaces pre-pass (iso-surfaces, AO); the counting variants (STATS 1 / 2) are not part of a timed frame
-FRAME_KERNELS = {"march": r"renderFrame(Kd)?Kernel<.*, 0(, (true|false))?>",
+_B = "(true|false)"
+FRAME_KERNELS = {"march": rf"renderFrameKdKernel<{_B}, {_B}, \d, {_B}, 0, {_B}(, \d)?>|renderFrameKernel<{_B}, {_B}, 0>",   # <GRAD, FAST, MULTI, SURF, STATS, SMALL, NCH> / <GRAD, ISO, STATS>
                  "march_wide": r"renderFrameKdWideKernel<",
                  "surfaces_prepass": r"surfacePrepassKdKernel<0>"}
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "SQ_INSTS_VALU"))     # HBM reads alone (MI355X_MICROARCH.md: separate passes)

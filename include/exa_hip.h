@@ -255,7 +255,10 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * a DVR march of 2..4 primary channels reads a channel-interleaved copy float[cell][channel] of those fields (built on
  * the device at the first such frame) and evaluates all channels per brick visit, 0 = field by field from the arrays
  * as uploaded; "addr64" 1 = the march forms 64-bit cell / header / node addresses even where a scene is small enough for
- * 32-bit offsets from a uniform base (default 0: chosen per scene; tests); "tile_feedback" 1 (default) = after a
+ * 32-bit offsets from a uniform base (default 0: chosen per scene; tests); "brick_order" 0 = the bricks' cells lie in
+ * memory in the order of the brick list (the running `begin` of OptixRenderer.cpp:71-93), 1 = along a Morton curve of the
+ * brick centres (re-laid on the device at the next frame; cells are only found through their brick's `begin`, so pixels
+ * cannot change; environment EXA_BRICK_ORDER sets the initial value); "tile_feedback" 1 (default) = after a
  * change of view / TF / layout the next synchronous frame records every tile's longest ray and later frames launch
  * the heaviest tiles first (a frame's critical path is its longest rays), 0 = keep the static order; "wide_march" 1
  * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes

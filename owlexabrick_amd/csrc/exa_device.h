@@ -196,6 +196,10 @@ hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay
 hipError_t launchKdRefit(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
 // computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel
 hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s);
+// brick b's cells from srcBegin[b] to dstBegin[b] in every field (src -> dst), then `begin` of every brick record / march header
+hipError_t launchPermuteBricks(const float *src, float *dst, const uint32_t *srcBegin, const uint32_t *dstBegin, int4 *bricks,
+                               unsigned long long numBricks, int4 *leafHdr, const int32_t *leafList, unsigned long long leafListSize,
+                               unsigned long long totalCells, int numFields, hipStream_t s);
 // out[cell * nch + c] = scalars[channelOffset[c] + cell] for c < nch
 hipError_t launchInterleave(const DeviceScene &sc, unsigned long long totalCells, int nch, float *out, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,

@@ -2631,6 +2631,40 @@ hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const 
 }
 
 // ------------------------------------------------------------------------
+// Re-laying the cell values brick by brick (option brick_order): brick b's cells move from srcBegin[b] to dstBegin[b] in
+// every field; then the `begin` words of the brick records and of the march headers are patched.  The kernels find a
+// cell only through its brick's `begin` (exabrick.cu:581-594, Brick.h:57-70), so the order of the bricks in memory is the
+// module's to choose.
+// ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void permuteBricksKernel(const float *src, float *dst, const uint32_t *srcBegin, const uint32_t *dstBegin,
+                                                           const int4 *bricks, unsigned long long totalCells, int numFields)
+{
+  const size_t b = blockIdx.x;
+  const int4 b0 = bricks[2 * b], b1 = bricks[2 * b + 1];           // (lower.xyz, size.x) (size.yz, level, begin)
+  const unsigned long long vol = (unsigned long long)b0.w * (unsigned long long)b1.x * (unsigned long long)b1.y;
+  const unsigned long long sb = srcBegin[b], db = dstBegin[b];
+  for (int f = 0; f < numFields; f++)
+    for (unsigned long long i = threadIdx.x; i < vol; i += 256) dst[f * totalCells + db + i] = src[f * totalCells + sb + i];
+}
+__global__ __launch_bounds__(256) void patchBeginKernel(int4 *bricks, unsigned long long numBricks, int4 *leafHdr, const int32_t *leafList,
+                                                        unsigned long long leafListSize, const uint32_t *dstBegin)
+{
+  const unsigned long long i = blockIdx.x * 256ull + threadIdx.x;
+  if (i < numBricks) bricks[2 * i + 1].w = (int)dstBegin[i];
+  if (i < leafListSize) leafHdr[2 * i + 1].w = (int)dstBegin[leafList[i]];
+}
+hipError_t launchPermuteBricks(const float *src, float *dst, const uint32_t *srcBegin, const uint32_t *dstBegin, int4 *bricks,
+                               unsigned long long numBricks, int4 *leafHdr, const int32_t *leafList, unsigned long long leafListSize,
+                               unsigned long long totalCells, int numFields, hipStream_t s)
+{
+  if (numBricks == 0) return hipSuccess;
+  hipLaunchKernelGGL(permuteBricksKernel, dim3((unsigned)numBricks), dim3(256), 0, s, src, dst, srcBegin, dstBegin, bricks, totalCells, numFields);
+  const unsigned long long n = numBricks > leafListSize ? numBricks : leafListSize;
+  hipLaunchKernelGGL(patchBeginKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, bricks, numBricks, leafHdr, leafList, leafListSize, dstBegin);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------
 // channel-interleaved copy of the primary channels for the multi-channel march: out[cell][c] = field_c[cell]
 // (exabrick.cu:581-594 reads field c at scalarBuffers[offset[c] + index]; the copy only changes where a value lives)
 // ------------------------------------------------------------------------

@@ -219,6 +219,32 @@ struct ExaHipRenderer {
   int interleave = 1;                // option "interleave"
   int addr64 = 0;                    // option "addr64": the general 64-bit address form even where 32-bit offsets would do (tests)
   uint64_t totalCells = 0;
+  // Order of the bricks' cells in memory (option brick_order): 0 = as uploaded (the running `begin` of
+  // OptixRenderer.cpp:71-93), 1 = along a Morton curve of the brick centres.  Cells are only ever found through their
+  // brick's `begin`, so the module may move them; switching re-lays the fields on the device.
+  std::vector<uint32_t> beginUploaded, beginMorton;   // per brick
+  int brickOrder = 0, brickOrderWanted = 0;
+  uint64_t numBricks = 0, leafListSize = 0;
+  int applyBrickOrder(hipStream_t s)
+  {
+    if (brickOrderWanted == brickOrder) return 0;
+    const std::vector<uint32_t> &from = brickOrder ? beginMorton : beginUploaded, &to = brickOrderWanted ? beginMorton : beginUploaded;
+    HIP_TRY(this, hipStreamSynchronize(s));
+    HIP_TRY(this, hipDeviceSynchronize());                 // frames in flight on other streams read the old layout
+    DevBuf<uint32_t> dFrom, dTo;
+    DevBuf<float> moved;
+    HIP_TRY(this, dFrom.upload(from.data(), from.size()));
+    HIP_TRY(this, dTo.upload(to.data(), to.size()));
+    HIP_TRY(this, moved.alloc(scalars.n));
+    HIP_TRY(this, launchPermuteBricks(scalars.p, moved.p, dFrom.p, dTo.p, bricks.p, numBricks, leafHdr.p, leafList.p, leafListSize,
+                                      totalCells, numFields, s));
+    HIP_TRY(this, hipStreamSynchronize(s));
+    std::swap(scalars.p, moved.p);                         // `moved` now owns the old array and frees it
+    sc.scalars = scalars.p;
+    brickOrder = brickOrderWanted;
+    ilChannels = 0; cellsIl.release();                     // the interleaved copy follows the new order
+    return 0;
+  }
   DevBuf<RegionInfo> regionInfo;
   DevBuf<float2> valueRange;
   DevBuf<float> domain;
@@ -611,6 +637,7 @@ struct ExaHipRenderer {
       xfDirty = false;
     }
     if (needLbvh() && ensureLbvh()) return 1;
+    if (applyBrickOrder(s)) return 1;
     {
       const int want = (useKd() && interleave && p.numPrimaryChannels >= 2 && p.numPrimaryChannels <= 4) ? p.numPrimaryChannels : 0;
       if (want != ilChannels) {
@@ -863,6 +890,39 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
 
   h->numFields = scene->numFields;
   h->totalCells = scene->totalCells;
+  h->numBricks = scene->numBricks; h->leafListSize = scene->leafListSize;
+  {
+    // brick orders: as uploaded, and along a Morton curve of the brick centres (21 bits per axis over the voxel bounds;
+    // equal codes keep the uploaded order), with a running `begin` as the reference assigns it (OptixRenderer.cpp:71-93)
+    const uint64_t nb = scene->numBricks;
+    h->beginUploaded.resize(nb);
+    std::vector<std::pair<uint64_t, uint32_t>> keyed(nb);
+    for (uint64_t b = 0; b < nb; b++) {
+      const ExaBrick &B = scene->bricks[b];
+      h->beginUploaded[b] = B.begin;
+      uint64_t code = 0;
+      for (int k = 0; k < 3; k++) {
+        const double cw = double(1u << B.level);
+        const double c = double(B.lower[k]) + 0.5 * cw * double(B.size[k]);
+        const double ext = double(scene->voxelBounds_hi[k]) - double(scene->voxelBounds_lo[k]);
+        double u = ext > 0 ? (c - double(scene->voxelBounds_lo[k])) / ext : 0.0;
+        u = std::min(std::max(u, 0.0), 1.0);
+        code |= LbvhTopology::spread21(std::min<uint64_t>(uint64_t(u * 2097152.0), 2097151ull)) << k;
+      }
+      keyed[b] = { code, uint32_t(b) };
+    }
+    std::sort(keyed.begin(), keyed.end());
+    h->beginMorton.resize(nb);
+    uint64_t at = 0;
+    for (uint64_t i = 0; i < nb; i++) {
+      const ExaBrick &B = scene->bricks[keyed[i].second];
+      h->beginMorton[keyed[i].second] = uint32_t(at);
+      at += uint64_t(B.size[0]) * uint64_t(B.size[1]) * uint64_t(B.size[2]);
+    }
+    // bricks that share cells or leave gaps (nothing the reference's loader produces) keep the uploaded order
+    if (at != scene->totalCells) h->beginMorton = h->beginUploaded;
+    if (const char *e = std::getenv("EXA_BRICK_ORDER")) h->brickOrderWanted = std::atoi(e) != 0;
+  }
   for (int k = 0; k < 3; k++) { h->voxLo[k] = scene->voxelBounds_lo[k]; h->voxHi[k] = scene->voxelBounds_hi[k]; }
   static_assert(sizeof(ExaBrick) == 2 * sizeof(int4), "brick = two int4");
   CREATE_TRY(h->bricks.upload(reinterpret_cast<const int4 *>(scene->bricks), scene->numBricks * 2));
@@ -1367,6 +1427,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "fast_sampler")) { h->fastSampler = value; return 0; }
   if (!std::strcmp(key, "interleave")) { h->interleave = value != 0; return 0; }
   if (!std::strcmp(key, "addr64")) { h->addr64 = value != 0; return 0; }
+  if (!std::strcmp(key, "brick_order")) { h->brickOrderWanted = value != 0; return 0; }
   if (!std::strcmp(key, "tf_filter")) {
     if (value != 0 && value != 1) { h->fail("exa_hip_set_option: tf_filter is 0 or 1"); return 1; }
     if (value != h->tfFilter) { h->tfFilter = value; h->volDirty = true; }     // region activity goes through the TF lookup

@@ -52,11 +52,14 @@ def test_pmc_frame_totals_sum_the_kernels_of_a_frame(tmp_path):
     march kernel (STATS template argument 0); the wide-march and surfaces pre-pass dispatches are the same frames' work
     and are reported per frame by class; the instrumented variant and other kernels are left out"""
     import importlib.util
+    import re
     spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    shipped = "void exa::renderFrameKdKernel<true, true, 0, false, 0, true>(exa::RenderArgs)"
-    counted = "void exa::renderFrameKdKernel<true, true, 0, false, 1, false>(exa::RenderArgs)"
+    shipped = "void exa::renderFrameKdKernel<true, true, 0, false, 0, true, 0>(exa::RenderArgs)"
+    counted = "void exa::renderFrameKdKernel<true, true, 0, false, 1, false, 0>(exa::RenderArgs)"
+    il3 = "void exa::renderFrameKdKernel<true, true, 2, false, 0, true, 3>(exa::RenderArgs)"
+    assert all(re.search(bench.FRAME_KERNELS["march"], k) for k in (shipped, il3)) and not re.search(bench.FRAME_KERNELS["march"], counted)
     wide = "void exa::renderFrameKdWideKernel<true, true, false, 4, true>(exa::RenderArgs)"
     pre = "void exa::surfacePrepassKdKernel<0>(exa::RenderArgs)"
     rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value"]

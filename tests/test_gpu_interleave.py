@@ -69,3 +69,32 @@ def test_changing_the_number_of_primary_channels_rebuilds_the_copy():
         R2.params.numPrimaryChannels = n
         assert np.array_equal(R2.render(), want), n
         R2.close()
+
+
+@pytest.mark.parametrize("nf", [1, 3])
+def test_brick_order_in_memory_does_not_change_the_frame(nf):
+    """option brick_order: the cells re-laid along a Morton curve of the brick centres (and back) on one handle; a scene
+    whose brick list is shuffled, so that the two orders really differ"""
+    sc = _scene(nf, seed=4)
+    rng = np.random.default_rng(7)
+    nb = sc.bricks7.shape[0]
+    perm = rng.permutation(nb)
+    vol = sc.bricks7[:, 0] * sc.bricks7[:, 1] * sc.bricks7[:, 2]
+    begin = np.concatenate([[0], np.cumsum(vol)])[:-1]
+    ids = np.concatenate([np.asarray(sc.cellIDs[begin[b]:begin[b] + vol[b]]) for b in perm])
+    sc.bricks7 = np.ascontiguousarray(sc.bricks7[perm])
+    sc.cellIDs = np.ascontiguousarray(ids)
+    kw = dict(W=96, H=72, grad=1, iso=[(0.4, 0)])
+    case = Case(sc, **kw)
+    R = case.hip_renderer()
+    ref = R.render().copy()
+    for order in (1, 0, 1):
+        R.setOption("brick_order", order)
+        assert np.array_equal(R.render(), ref), order
+    rgba, st = R.renderStats()                       # the counting variant and the literal sampler read the brick records
+    assert np.array_equal(rgba, ref)
+    R.setOption("accel", 0)                          # LBVH path: literal addBasisFunctions on the brick records
+    lb = R.render().copy()
+    R.setOption("brick_order", 0)
+    assert np.array_equal(R.render(), lb)
+    R.close()
