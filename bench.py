@@ -107,7 +107,7 @@ def spawn_ranks(n):
 _B = "(true|false)"
 FRAME_KERNELS = {"march": rf"renderFrameKdKernel<{_B}, {_B}, \d, {_B}, 0, {_B}(, \d)?>|renderFrameKernel<{_B}, {_B}, 0>",   # <GRAD, FAST, MULTI, SURF, STATS, SMALL, NCH> / <GRAD, ISO, STATS>
                  "march_wide": r"renderFrameKdWideKernel<",
-                 "surfaces_prepass": r"surfacePrepassKdKernel<0>"}
+                 "surfaces_prepass": r"surfacePrepassKdKernel<0, (true|false)>"}
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "SQ_INSTS_VALU"))     # HBM reads alone (MI355X_MICROARCH.md: separate passes)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0       # G wave64-VALU instructions / s: 1024 SIMDs, one every 2 cycles, 2.4 GHz
 F32_VECTOR_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 vector peak (FMA counted as 2)

@@ -125,6 +125,10 @@ typedef struct ExaHipStats {
                              epilogue, kd walk, segment pop, other (ray set-up, output) */
   float    kernel_ms;     /* hipEvent time of the last render launch               */
   float    rebuild_ms;    /* hipEvent time of the last activity+refit pass         */
+  uint64_t walk_restarts;     /* kd walk: restarts from the root after the 4-entry short stack dropped an entry */
+  uint64_t walk_union_nodes;  /* option walk_probe: kd nodes visited, counted once per WAVE (the union over its 64 rays):
+                                 what a wave-coherent (packet) walk would have to step through at least */
+  uint64_t walk_probe_overflow; /* ... lanes that found their wave's probe table full (0 in a valid measurement) */
 } ExaHipStats;
 
 typedef struct ExaHipRenderer ExaHipRenderer;
@@ -265,7 +269,9 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * per ray — the walk split into depth windows, consecutive samples evaluated side by side and composited in order,
  * bit-identical pixels; up to 8 GiB of device memory for the walkers' leaf lists — 0 = never,
  * 2 / 4 = every tile with that many lanes (tests); "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
- * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change.
+ * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change; "walk_probe" 1 = the
+ * counting variant also records every wave's SET of visited kd nodes (128 KiB of device memory per wave) and reports its
+ * size summed over the waves as walk_union_nodes (a diagnostic of how coherent the 64 walks of a wave are).
  * Two knobs move results within the stated float tolerance: "fast_math" 1 (default)
  * evaluates the opacity correction powf as exp2(dt*log2(x)) on the hardware
  * transcendental units (~2 ulp), 0 uses the library powf (<1 ulp); "tf_filter" 1 (default) holds the

@@ -38,6 +38,9 @@
 #ifndef EXA_IL34_WAVES
 #define EXA_IL34_WAVES 4       // ... and with three or four (their cell values and sums need the registers)
 #endif
+#ifndef EXA_PREPASS_ISO_WAVES
+#define EXA_PREPASS_ISO_WAVES 4 // ... and its variant for frames whose only surfaces are implicit iso-surfaces
+#endif
 #ifndef EXA_OPT_MED3
 #define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
 #endif
@@ -112,7 +115,8 @@ struct DeviceScene {
 #endif
 enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kKdStackMulti = EXA_KD_STACK_MULTI, kSegQueue = EXA_SEG_QUEUE,
        kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
-       kWideSegCap = 256 };   // wide march: leaves a window walker lists per round (16 B each; a fuller window takes more rounds)
+       kWideSegCap = 256,
+       kWalkProbeBits = 15, kWalkProbeSize = 1 << kWalkProbeBits };   // walk probe: entries of a wave's node set   // wide march: leaves a window walker lists per round (16 B each; a fuller window takes more rounds)
 
 enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CORNER_LOADS,
                 ST_ISO_SEGMENTS, ST_ISO_EVALS, ST_NODES,
@@ -122,7 +126,8 @@ enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CO
                 ST_KD_MISMATCH,
                 // shader-clock cycles of the waves by phase (sum over waves): brick visit, sample epilogue, kd walk,
                 // segment pop, everything else (ray set-up, output)
-                ST_T_BRICK, ST_T_FINAL, ST_T_WALK, ST_T_SEG, ST_T_OTHER, ST_COUNT };
+                ST_T_BRICK, ST_T_FINAL, ST_T_WALK, ST_T_SEG, ST_T_OTHER,
+                ST_RESTARTS, ST_UNION, ST_PROBE_OVERFLOW, ST_COUNT };
 
 struct RenderArgs {
   DeviceScene        sc;
@@ -174,6 +179,7 @@ struct RenderArgs {
   int32_t            debugPixel;    // >= 0: only pixel x + W*y is rendered (debugging aid)
   const int32_t     *wideTileMap;   // wide march: launch slot / L -> global tile id
   float4            *wideSegs;      // wide march: [tile of this launch][ray][window][kWideSegCap] {record, tn, tf, -}
+  uint32_t          *walkProbe;     // != null (counting variant, option walk_probe): per wave a hash set of kWalkProbeSize node ids
   uint32_t          *tileCost;      // != null: per tile id, brick visits of the tile's longest ray (launch-order feedback)
 };
 

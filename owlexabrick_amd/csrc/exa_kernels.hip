@@ -108,6 +108,21 @@ struct Ctx {
   unsigned long long st[ST_COUNT];
   bool guardTripped;
   bool fastSampler = false;    // samplePoint: masked-weight basis on the march headers (kd kernels) or the literal form
+  uint32_t *probe = nullptr;   // walk probe (counting variant): this wave's set of visited kd nodes
+  // adds a node id to the wave's set (open addressing in global memory); new members are counted
+  __device__ __forceinline__ void probeNode(int ref)
+  {
+    if (STATS != 1 || !probe) return;
+    const uint32_t key = (uint32_t)ref + 1u;
+    uint32_t h = (key * 2654435761u) >> (32 - kWalkProbeBits);
+    for (int i = 0; i < kWalkProbeSize; i++) {
+      const uint32_t prev = atomicCAS(&probe[h], 0u, key);
+      if (prev == 0u) { st[ST_UNION]++; return; }
+      if (prev == key) return;
+      h = (h + 1u) & (kWalkProbeSize - 1u);
+    }
+    st[ST_PROBE_OVERFLOW]++;
+  }
   __device__ __forceinline__ void count(int slot, unsigned long long n = 1) { if (STATS == 1) st[slot] += n; }
   // wave time by phase (instrumented variant): the cycles since the wave's previous mark go to the phase that
   // mark opened; one lane of the active set keeps the books, the mark itself lives in LDS (per wave)
@@ -724,8 +739,8 @@ struct IsoResult { Color4 pixelColor; float t_hit; V3 gradient; };
 
 // exabrick.cu:1018-1114 IsoSurfaceIntegrationFunction::operator()
 template <int STATS>
-__device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, const Ray &ray, IsoResult &result,
-                        float t_sample, float cellValueIn, const RegionInfo &ri, int channel)
+__device__ void isoFunc(Ctx<STATS> &C, const float last_t, const float lastCellValue, const Ray &ray, IsoResult &result,
+                        float t_sample, float cellValueIn, const RegionInfo &ri, int channel, const bool hitOnly = false)
 {
   const ExaHipFrameState &fs = C.a->fs;
   if (lastCellValue >= -1e35f) {
@@ -738,6 +753,15 @@ __device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, cons
         const float w1 = 1.f - d1 / (d1 + d2);
         const float w2 = 1.f - d2 / (d1 + d2);
         const float tavg = last_t * w1 + t_sample * w2;
+        if (hitOnly && STATS != 1) {
+          // An ambient-occlusion ray only asks WHETHER and WHERE it hits (exabrick.cu:1640-1643 reads primID, the trace
+          // compares t_hit): colour and normal of the hit — the re-sampling at the crossing point, :1056-1085 — are
+          // never read.  What the rest of the march does see is the opacity, which the opaque sample (:1086) brings to
+          // (1 - w) * 1 + w whatever its colour, and the hit distance.  (The counting variant keeps the full form.)
+          result.pixelColor.w += (1.f - result.pixelColor.w) * 1.f * 1.f;
+          result.t_hit = tavg;
+          continue;
+        }
         float cellValue = 0.f;
         V3 grad = mk(0.f, 0.f, 0.f);
         Color4 sample; sample.x = 1.f; sample.y = 0.f; sample.z = 0.f; sample.w = 1.f;
@@ -778,9 +802,30 @@ __device__ void isoFunc(Ctx<STATS> &C, float &last_t, float &lastCellValue, cons
       }
     }
   }
-  last_t = t_sample;
-  lastCellValue = cellValueIn;
+  // last_t = t_sample; lastCellValue = cellValueIn (:1112-1113): the caller's IsoLast::set
 }
+
+// The functor state of traceIsoRay (IsoSurfaceIntegrationFunction[MAX_CHANNELS], exabrick.cu:1424): per channel the
+// previous sample's distance and value.  Only the channels an enabled iso-surface refers to are ever read (the crossing
+// test is behind `iso.channel == channel`, :1038), so two slots hold everything that is observable — in registers, where
+// an array indexed by the channel lives in scratch memory.
+struct IsoLast {
+  float t0, v0, t1, v1;
+  int ch0, ch1;                     // channel of slot 0 / 1 (-1: unused)
+  __device__ __forceinline__ void init(const ExaHipFrameState &fs)
+  {
+    t0 = t1 = 0.f; v0 = v1 = -1e36f;
+    ch0 = fs.iso[0].enabled ? fs.iso[0].channel : -1;
+    ch1 = (fs.iso[1].enabled && !(fs.iso[0].enabled && fs.iso[1].channel == fs.iso[0].channel)) ? fs.iso[1].channel : -1;
+  }
+  __device__ __forceinline__ float lastT(int c) const { return c == ch0 ? t0 : (c == ch1 ? t1 : 0.f); }
+  __device__ __forceinline__ float lastV(int c) const { return c == ch0 ? v0 : (c == ch1 ? v1 : -1e36f); }
+  __device__ __forceinline__ void set(int c, float t, float v)
+  {
+    if (c == ch0) { t0 = t; v0 = v; }
+    else if (c == ch1) { t1 = t; v1 = v; }
+  }
+};
 
 struct SurfaceHit { int primID; float t_hit; V3 Ng; float ambient; V3 baseColor; };
 #define EXA_PRIMID_ISOSURFACE (-23)
@@ -1010,8 +1055,8 @@ __device__ void traceStreamlines(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
 
 // exabrick.cu:1187-1256 isoIntegrateBrick
 template <int STATS>
-__device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellValue, IsoResult &ir, float off,
-                                  const Ray &ray, const RegionInfo &ri, float t0, float t1, int numChannels)
+__device__ void isoIntegrateBrick(Ctx<STATS> &C, IsoLast &last, IsoResult &ir, float off,
+                                  const Ray &ray, const RegionInfo &ri, float t0, float t1, int numChannels, const bool hitOnly = false)
 {
   unsigned isoChannelMask = 0;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++)
@@ -1033,12 +1078,14 @@ __device__ void isoIntegrateBrick(Ctx<STATS> &C, float *last_t, float *lastCellV
       if (STATS != 1 && !((isoChannelMask >> c) & 1u) && ir.pixelColor.w < EXA_TERMINATION_THRESHOLD) continue;
       float cellValue = 0.f;
       V3 grad = mk(0.f, 0.f, 0.f);
-      bool doIntegrate;
       C.count(ST_ISO_EVALS);
-      if (C.a->p.gradientShadingISO) doIntegrate = samplePoint<true, STATS>(C, cellValue, grad, ri, pos, c);
-      else                           doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
+      // The reference samples with the derivative here when gradientShadingISO is on (:1224-1231), but the functor never
+      // looks at it (:1019-1110 takes the gradient from its own re-sampling at the crossing point): value and validity
+      // are the same sums either way, so the step samples are taken without the derivative sums
+      const bool doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
       if (doIntegrate) {
-        isoFunc(C, last_t[c], lastCellValue[c], ray, ir, t_sample, cellValue, ri, c);
+        isoFunc(C, last.lastT(c), last.lastV(c), ray, ir, t_sample, cellValue, ri, c, hitOnly);
+        last.set(c, t_sample, cellValue);
         if (ir.pixelColor.w >= EXA_TERMINATION_THRESHOLD) break;   // leaves the channel loop only
       }
     }
@@ -1056,8 +1103,8 @@ __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
   const float dt_scale = length(ray.dir);
   ray.dir = normalize(ray.dir);
   float alreadyIntegratedDistance = dt_scale * ray.tmin;
-  float last_t[EXA_MAX_CHANNELS], lastCellValue[EXA_MAX_CHANNELS];
-  for (int c = 0; c < EXA_MAX_CHANNELS; c++) { last_t[c] = 0.f; lastCellValue[c] = -1e36f; }
+  IsoLast last;
+  last.init(fs);
   SurfaceHit result;
   result.primID = -1; result.t_hit = ray.tmax; result.Ng = mk(0.f, 0.f, 0.f);
   result.ambient = 0.f; result.baseColor = mk(0.f, 0.f, 0.f);
@@ -1072,7 +1119,7 @@ __device__ SurfaceHit traceIsoRay(Ctx<STATS> &C, Ray ray, float off)
     IsoResult ir;
     ir.pixelColor.x = ir.pixelColor.y = ir.pixelColor.z = ir.pixelColor.w = 0.f;
     ir.t_hit = -1.f; ir.gradient = mk(0.f, 0.f, 0.f);
-    isoIntegrateBrick(C, last_t, lastCellValue, ir, off, ray, ri, fmaxf(ray.tmin, prd.t0), fminf(ray.tmax, prd.t1),
+    isoIntegrateBrick(C, last, ir, off, ray, ri, fmaxf(ray.tmin, prd.t0), fminf(ray.tmax, prd.t1),
                       C.a->p.numPrimaryChannels);
     if (ir.t_hit >= 0.f) {
       result.primID = EXA_PRIMID_ISOSURFACE;
@@ -1331,6 +1378,7 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, 
     w.tn = stackF[(2 * head) * kKdBlock];
     w.tf = stackF[(2 * head + 1) * kKdBlock];
   } else if (w.pk.get(PK_DROPPED) && w.tf < w.tEnd) {
+    C.count(ST_RESTARTS);
     w.ref = root;                      // short-stack restart: everything before tf is done
     w.tn = w.tf;
     w.tf = w.tEnd;
@@ -1413,6 +1461,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
                        : *reinterpret_cast<const int4 *>(nodes + w.ref);
   C.count(ST_NODES);
   C.phase(ST_W_NODE);
+  C.probeNode(w.ref);
   const float split = __int_as_float(n.x);
   const int axis = n.y & 3;
   const int bits = (n.y >> (2 + 2 * which)) & 3;            // bit0 left active, bit1 right active
@@ -1462,7 +1511,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
 // ordered walk, one lane at a time refills its own queue here (the iso pre-pass is not the
 // headline path), the march is isoIntegrateBrick.
 template <int STATS>
-__device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *stackF, int *qRegion, float *qT)
+__device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *stackF, int *qRegion, float *qT, const bool hitOnly = false)
 {
   const RenderArgs &a = *C.a;
   const ExaHipFrameState &fs = a.fs;
@@ -1472,8 +1521,8 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
   ray.dir = normalize(ray.dir);
   float walkTmin = dt_scale * ray.tmin;
   float walkTmax = ray.tmax * dt_scale;                      // tmax of the first trace (:1434)
-  float last_t[EXA_MAX_CHANNELS], lastCellValue[EXA_MAX_CHANNELS];
-  for (int c = 0; c < EXA_MAX_CHANNELS; c++) { last_t[c] = 0.f; lastCellValue[c] = -1e36f; }
+  IsoLast last;
+  last.init(fs);
   SurfaceHit result;
   result.primID = -1; result.t_hit = ray.tmax; result.Ng = mk(0.f, 0.f, 0.f);
   result.ambient = 0.f; result.baseColor = mk(0.f, 0.f, 0.f);
@@ -1512,7 +1561,7 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
     IsoResult ir;
     ir.pixelColor.x = ir.pixelColor.y = ir.pixelColor.z = ir.pixelColor.w = 0.f;
     ir.t_hit = -1.f; ir.gradient = mk(0.f, 0.f, 0.f);
-    isoIntegrateBrick(C, last_t, lastCellValue, ir, off, ray, ri, t0, t1, a.p.numPrimaryChannels);
+    isoIntegrateBrick(C, last, ir, off, ray, ri, t0, t1, a.p.numPrimaryChannels, hitOnly);
     if (ir.t_hit >= 0.f) {
       result.primID = EXA_PRIMID_ISOSURFACE;
       result.t_hit = ir.t_hit / dt_scale;
@@ -1549,15 +1598,16 @@ __device__ int kdFindRegion(Ctx<STATS> &C, V3 pos, float *stackF, int *qRegion, 
   return w.pk.get(PK_QCOUNT) ? qRegion[w.pk.get(PK_QHEAD) * kKdBlock] : -1;
 }
 
-template <int STATS>
+// ISO_ONLY: the frame has no triangle meshes, contour planes or streamlines (the launcher checks): their code is left out
+template <int STATS, bool ISO_ONLY>
 __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd, bool withContourPlanes,
                                                 float *stackF, int *qRegion, float *qT)
 {
   prd.primID = -1;
   prd.t_hit = ray.tmax;
   prd.Ng = mk(0.f, 0.f, 0.f); prd.ambient = 0.f; prd.baseColor = mk(0.f, 0.f, 0.f);
-  if (C.a->numTris > 0) traceMeshes(C, ray, prd);                 // ST_MESHES (also for AO rays)
-  if (withContourPlanes) {
+  if (!ISO_ONLY && C.a->numTris > 0) traceMeshes(C, ray, prd);                 // ST_MESHES (also for AO rays)
+  if (!ISO_ONLY && withContourPlanes) {
     for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; ++i)
       if (C.a->fs.contour[i].enabled) {
         auto find = [&](V3 pos) { return kdFindRegion(C, pos, stackF, qRegion, qT); };
@@ -1566,11 +1616,12 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
         if (c.primID == EXA_PRIMID_PLANE && c.t_hit < prd.t_hit) prd = c;
       }
   }
-  if (C.a->numStreamPrims > 0) traceStreamlines(C, ray, prd);     // ST_STREAMLINES (:1503-1512)
+  if (!ISO_ONLY && C.a->numStreamPrims > 0) traceStreamlines(C, ray, prd);     // ST_STREAMLINES (:1503-1512)
   bool activeIso = false;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
   if (activeIso) {
-    const SurfaceHit isoPRD = traceIsoRayKd(C, ray, 0.f, stackF, qRegion, qT);
+    // the rays traced without contour planes are the ambient-occlusion rays (:1638): only hit / no hit is read
+    const SurfaceHit isoPRD = traceIsoRayKd(C, ray, 0.f, stackF, qRegion, qT, !withContourPlanes);
     if (isoPRD.primID == EXA_PRIMID_ISOSURFACE && isoPRD.t_hit < prd.t_hit) prd = isoPRD;
   }
 }
@@ -1582,8 +1633,8 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
 // to it through a[].surf / surfRnd: the generic surface code needs ~130 VGPRs, the march 80, and one
 // fused kernel would run the march at half its occupancy.
 // ------------------------------------------------------------------------
-template <int STATS>
-__global__ __launch_bounds__(kKdBlock, EXA_PREPASS_WAVES) void surfacePrepassKdKernel(const RenderArgs a)
+template <int STATS, bool ISO_ONLY>
+__global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_PREPASS_WAVES)) void surfacePrepassKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -1633,7 +1684,7 @@ __global__ __launch_bounds__(kKdBlock, EXA_PREPASS_WAVES) void surfacePrepassKdK
     float surface_t_hit = ray.tmax;
     {
       SurfaceHit surface;
-      traceSurfacesKd(C, ray, surface, true, stackF, qRegion, qT);
+      traceSurfacesKd<STATS, ISO_ONLY>(C, ray, surface, true, stackF, qRegion, qT);
       surface_t_hit = surface.t_hit;
       if (surface.primID >= 0 || surface.primID == EXA_PRIMID_ISOSURFACE || surface.primID == EXA_PRIMID_PLANE
           || surface.primID == EXA_PRIMID_STREAMLINE) {
@@ -1657,7 +1708,7 @@ __global__ __launch_bounds__(kKdBlock, EXA_PREPASS_WAVES) void surfacePrepassKdK
             ao_ray.dir = normalize((sp.x * uN + sp.y * vN) + sp.z * wN);
             ao_ray.tmin = 1e-4f; ao_ray.tmax = AO_Radius;
             SurfaceHit ao;
-            traceSurfacesKd(C, ao_ray, ao, false, stackF, qRegion, qT);
+            traceSurfacesKd<STATS, ISO_ONLY>(C, ao_ray, ao, false, stackF, qRegion, qT);
             if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE
                 || ao.primID == EXA_PRIMID_STREAMLINE) hitCnt++;
           }
@@ -1736,6 +1787,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
   const int px = tx * kTile + inX, py = ty * kTile + inY;
   const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
 
+  if (STATS == 1 && a.walkProbe) C.probe = a.walkProbe + size_t(gwave) * kWalkProbeSize;
   unsigned marchIters = 0;
   if (inside) {
     const ExaHipFrameState &fs = a.fs;
@@ -2380,8 +2432,11 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
   if (numBlocks <= 0) return hipSuccess;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
-  if (stats) hipLaunchKernelGGL((surfacePrepassKdKernel<1>), grid, block, lds, s, a);
-  else       hipLaunchKernelGGL((surfacePrepassKdKernel<0>), grid, block, lds, s, a);
+  bool isoOnly = a.numTris == 0 && a.numStreamPrims == 0;
+  for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; i++) isoOnly = isoOnly && !a.fs.contour[i].enabled;
+  if (stats)        hipLaunchKernelGGL((surfacePrepassKdKernel<1, false>), grid, block, lds, s, a);
+  else if (isoOnly) hipLaunchKernelGGL((surfacePrepassKdKernel<0, true>), grid, block, lds, s, a);
+  else              hipLaunchKernelGGL((surfacePrepassKdKernel<0, false>), grid, block, lds, s, a);
   return hipGetLastError();
 }
 

@@ -325,6 +325,8 @@ struct ExaHipRenderer {
   bool layoutDirty = true;
 
   DevBuf<unsigned long long> statsBuf;
+  int walkProbeOn = 0;                  // option walk_probe
+  DevBuf<uint32_t> walkProbe;
   DevBuf<int32_t> errorFlag;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
   ExaHipStats last{};
@@ -772,6 +774,13 @@ struct ExaHipRenderer {
     a.stats = statsBuf.p;
     a.errorFlag = errorFlag.p;
     a.debugPixel = debugPixel;
+    a.walkProbe = nullptr;
+    if (stats && statsMode == 1 && walkProbeOn && useKd()) {
+      const size_t need = size_t(numBlocks) * (256 / 64) * kWalkProbeSize;
+      if (walkProbe.n != need) HIP_TRY(this, walkProbe.alloc(need));
+      HIP_TRY(this, hipMemsetAsync(walkProbe.p, 0, need * sizeof(uint32_t), s));
+      a.walkProbe = walkProbe.p;
+    }
     a.tileCost = nullptr;
     if (feedback && costPhase == 1 && useKd() && measureCosts) {
       HIP_TRY(this, hipMemsetAsync(tileCost.p, 0, tileCost.n * sizeof(uint32_t), s));
@@ -1417,6 +1426,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     if (value != 1 && value != 2) { h->fail("exa_hip_set_option: stats_mode is 1 or 2"); return 1; }
     h->statsMode = value; return 0;
   }
+  if (!std::strcmp(key, "walk_probe")) { h->walkProbeOn = value != 0; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
   if (!std::strcmp(key, "lbvh_build")) {              // 0 = on the device (default), 1 = on the host; before the first LBVH frame
@@ -1493,6 +1503,7 @@ static int renderMulti(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, 
       sum.iso_segments += k[ST_ISO_SEGMENTS]; sum.iso_evals += k[ST_ISO_EVALS]; sum.nodes_visited += k[ST_NODES];
       for (int i = 0; i < 9; i++) sum.diag[i] += k[ST_W_BRICK + i];
       for (int i = 0; i < 5; i++) sum.phase_cycles[i] += k[ST_T_BRICK + i];
+      sum.walk_restarts += k[ST_RESTARTS]; sum.walk_union_nodes += k[ST_UNION]; sum.walk_probe_overflow += k[ST_PROBE_OVERFLOW];
     }
   }
   sum.pixels = uint64_t(h->W) * h->H;
@@ -1502,6 +1513,7 @@ static int renderMulti(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, 
     sum.corner_loads = keep.corner_loads; sum.iso_segments = keep.iso_segments; sum.iso_evals = keep.iso_evals; sum.nodes_visited = keep.nodes_visited;
     for (int i = 0; i < 9; i++) sum.diag[i] = keep.diag[i];
     for (int i = 0; i < 5; i++) sum.phase_cycles[i] = keep.phase_cycles[i];
+    sum.walk_restarts = keep.walk_restarts; sum.walk_union_nodes = keep.walk_union_nodes; sum.walk_probe_overflow = keep.walk_probe_overflow;
   }
   h->last = sum;
   if (!dstIsDevice && rgba8) {
@@ -1543,6 +1555,8 @@ static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, h
     h->last.iso_segments = c[ST_ISO_SEGMENTS]; h->last.iso_evals = c[ST_ISO_EVALS]; h->last.nodes_visited = c[ST_NODES];
     for (int i = 0; i < 9; i++) h->last.diag[i] = c[ST_W_BRICK + i];
     for (int i = 0; i < 5; i++) h->last.phase_cycles[i] = c[ST_T_BRICK + i];
+    h->last.walk_restarts = c[ST_RESTARTS]; h->last.walk_union_nodes = c[ST_UNION]; h->last.walk_probe_overflow = c[ST_PROBE_OVERFLOW];
+    h->walkProbe.release();
   }
   h->last.pixels = px;
   return 0;

@@ -61,7 +61,7 @@ def test_pmc_frame_totals_sum_the_kernels_of_a_frame(tmp_path):
     il3 = "void exa::renderFrameKdKernel<true, true, 2, false, 0, true, 3>(exa::RenderArgs)"
     assert all(re.search(bench.FRAME_KERNELS["march"], k) for k in (shipped, il3)) and not re.search(bench.FRAME_KERNELS["march"], counted)
     wide = "void exa::renderFrameKdWideKernel<true, true, false, 4, true>(exa::RenderArgs)"
-    pre = "void exa::surfacePrepassKdKernel<0>(exa::RenderArgs)"
+    pre = "void exa::surfacePrepassKdKernel<0, true>(exa::RenderArgs)"
     rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value"]
     rows += [f'1,1,0,"{counted}",FETCH_SIZE,1000.0']
     rows += [f'2,2,0,"{shipped}",FETCH_SIZE,10.0', f'2,2,0,"{shipped}",FETCH_SIZE,30.0']       # two instances

@@ -11,7 +11,7 @@ import sys
 out, key = sys.argv[1], sys.argv[2]
 txt = open(os.path.join(out, "summary.txt")).read()
 # the shipped march: STATS template argument 0 (the last-but-one argument since round 2, the last before)
-blk = [b for b in txt.split("== ") if b.startswith("void exa::renderFrame") and re.search(r", 0(, (true|false))?>", b.split("\n")[0])][0]
+blk = [b for b in txt.split("== ") if b.startswith("void exa::renderFrame") and re.search(r", 0, (true|false)(, \d)?>", b.split("\n")[0])][0]
 fetch = float(re.search(r"FETCH_SIZE\s+([0-9.e+]+)", blk).group(1))
 write = float(re.search(r"WRITE_SIZE\s+([0-9.e+]+)", blk).group(1))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
