@@ -39,7 +39,9 @@
 #define EXA_IL34_WAVES 4       // ... and with three or four (their cell values and sums need the registers)
 #endif
 #ifndef EXA_PREPASS_ISO_WAVES
-#define EXA_PREPASS_ISO_WAVES 4 // ... and its variant for frames whose only surfaces are implicit iso-surfaces
+#define EXA_PREPASS_ISO_WAVES 3 // ... and its variant for frames whose only surfaces are implicit iso-surfaces: bound by the latency of its
+                                // longest rays, not by throughput (C3: 3 / 4 / 5 waves 21.08 / 21.07 / 21.62 ms per frame), so it takes
+                                // the registers that keep a one-brick region's march header across the segment
 #endif
 #ifndef EXA_OPT_MED3
 #define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
@@ -180,6 +182,7 @@ struct RenderArgs {
   const int32_t     *wideTileMap;   // wide march: launch slot / L -> global tile id
   float4            *wideSegs;      // wide march: [tile of this launch][ray][window][kWideSegCap] {record, tn, tf, -}
   uint32_t          *walkProbe;     // != null (counting variant, option walk_probe): per wave a hash set of kWalkProbeSize node ids
+  uint32_t          *tileCostPre;   // != null: per tile id, steps of the longest iso march of the surfaces pre-pass
   uint32_t          *tileCost;      // != null: per tile id, brick visits of the tile's longest ray (launch-order feedback)
 };
 

@@ -108,6 +108,7 @@ struct Ctx {
   unsigned long long st[ST_COUNT];
   bool guardTripped;
   bool fastSampler = false;    // samplePoint: masked-weight basis on the march headers (kd kernels) or the literal form
+  unsigned isoSteps = 0;       // steps of this lane's iso marches (pre-pass cost of its pixel, for the launch plan)
   uint32_t *probe = nullptr;   // walk probe (counting variant): this wave's set of visited kd nodes
   // adds a node id to the wave's set (open addressing in global memory); new members are counted
   __device__ __forceinline__ void probeNode(int ref)
@@ -1054,18 +1055,26 @@ __device__ void traceStreamlines(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
 }
 
 // exabrick.cu:1187-1256 isoIntegrateBrick
-template <int STATS>
+template <int STATS, bool CACHE_HDR = false>
 __device__ void isoIntegrateBrick(Ctx<STATS> &C, IsoLast &last, IsoResult &ir, float off,
                                   const Ray &ray, const RegionInfo &ri, float t0, float t1, int numChannels, const bool hitOnly = false)
 {
   unsigned isoChannelMask = 0;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++)
     if (C.a->fs.iso[i].enabled) isoChannelMask |= 1u << (C.a->fs.iso[i].channel & 31);
+  // A region of one brick (most of them) keeps its march header in registers for the whole segment: the pre-pass is bound
+  // by the LATENCY of its longest rays' dependent steps (on C3 it issues 0.3 G vector instructions in 3.6 ms), and the
+  // header load in front of every sample's cell loads was one of the two dependent memory round trips of a step
+  // (CACHE_HDR: the iso-only pre-pass; with the mesh / contour / streamline code around it the eight registers spill)
+  const bool oneBrick = CACHE_HDR && C.fastSampler && ri.listSize == 1;
+  int4 hdr0 = make_int4(0, 0, 0, 0), hdr1 = make_int4(1, 1, 1, 0);
+  if (oneBrick) { hdr0 = C.a->sc.leafHdr[2u * (unsigned)ri.listBegin]; hdr1 = C.a->sc.leafHdr[2u * (unsigned)ri.listBegin + 1u]; }
   const float dt = C.a->p.dt * ri.finestLevelCellWidth;
   float t_i = firstSampleT(t0, dt, off);
   float t_last = t0;
   for (int step = 0;; t_i += dt, step++) {
     if (step >= EXA_MAX_STEPS) { C.guardTripped = true; break; }
+    C.isoSteps++;
     const float t_next = fminf(t_i, t1);
     const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
     t_last = t_next;
@@ -1082,7 +1091,16 @@ __device__ void isoIntegrateBrick(Ctx<STATS> &C, IsoLast &last, IsoResult &ir, f
       // The reference samples with the derivative here when gradientShadingISO is on (:1224-1231), but the functor never
       // looks at it (:1019-1110 takes the gradient from its own re-sampling at the crossing point): value and validity
       // are the same sums either way, so the step samples are taken without the derivative sums
-      const bool doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
+      bool doIntegrate;
+      if (oneBrick) {
+        Basis B;
+        B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+        addBasisFast<false, STATS, false>(C, B, hdr0, hdr1, C.a->sc.scalars + C.a->sc.channelOffset[c], pos);
+        doIntegrate = B.sumW > 1e-20f;                                   // samplePoint (:800-806)
+        if (doIntegrate) cellValue = B.sumWV / B.sumW;
+      } else {
+        doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
+      }
       if (doIntegrate) {
         isoFunc(C, last.lastT(c), last.lastV(c), ray, ir, t_sample, cellValue, ri, c, hitOnly);
         last.set(c, t_sample, cellValue);
@@ -1510,7 +1528,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
 // exabrick.cu:1408-1460 traceIsoRay on the kd walk (iso activity bits): segments come out of the
 // ordered walk, one lane at a time refills its own queue here (the iso pre-pass is not the
 // headline path), the march is isoIntegrateBrick.
-template <int STATS>
+template <int STATS, bool CACHE_HDR = false>
 __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *stackF, int *qRegion, float *qT, const bool hitOnly = false)
 {
   const RenderArgs &a = *C.a;
@@ -1561,7 +1579,7 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
     IsoResult ir;
     ir.pixelColor.x = ir.pixelColor.y = ir.pixelColor.z = ir.pixelColor.w = 0.f;
     ir.t_hit = -1.f; ir.gradient = mk(0.f, 0.f, 0.f);
-    isoIntegrateBrick(C, last, ir, off, ray, ri, t0, t1, a.p.numPrimaryChannels, hitOnly);
+    isoIntegrateBrick<STATS, CACHE_HDR>(C, last, ir, off, ray, ri, t0, t1, a.p.numPrimaryChannels, hitOnly);
     if (ir.t_hit >= 0.f) {
       result.primID = EXA_PRIMID_ISOSURFACE;
       result.t_hit = ir.t_hit / dt_scale;
@@ -1621,7 +1639,7 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
   if (activeIso) {
     // the rays traced without contour planes are the ambient-occlusion rays (:1638): only hit / no hit is read
-    const SurfaceHit isoPRD = traceIsoRayKd(C, ray, 0.f, stackF, qRegion, qT, !withContourPlanes);
+    const SurfaceHit isoPRD = traceIsoRayKd<STATS, ISO_ONLY>(C, ray, 0.f, stackF, qRegion, qT, !withContourPlanes);
     if (isoPRD.primID == EXA_PRIMID_ISOSURFACE && isoPRD.t_hit < prd.t_hit) prd = isoPRD;
   }
 }
@@ -1729,6 +1747,12 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
     a.surfRnd[slot] = rnd.state;
   }
 
+  if (a.tileCostPre) {
+    // launch plan: the longest iso march of this tile, in steps (the pre-pass is bound by its longest rays)
+    unsigned v = inside ? C.isoSteps : 0u;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down((int)v, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(&a.tileCostPre[tile], v);
+  }
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
   if (STATS) {
     for (int i = 0; i < ST_COUNT; i++) {

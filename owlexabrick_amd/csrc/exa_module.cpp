@@ -306,6 +306,16 @@ struct ExaHipRenderer {
   DevBuf<float4> accum;
   DevBuf<float4> surf;
   DevBuf<uint32_t> tileCost;            // launch-order feedback, one entry per tile of the image
+  // Launch plan of a frame with surfaces (option prepass_split, default 1).  The surfaces pre-pass is bound by the LATENCY
+  // of its longest iso marches (C3: 0.3 G vector instructions in 3.6 ms), the march behind it by throughput.  The frame
+  // that measures tile costs also records every tile's longest iso march; afterwards the few tiles with long pre-pass
+  // rays ("heavy") get their own pre-pass + march pipeline on a side stream, which runs beside the pre-pass + march of
+  // all other tiles instead of in front of it.  Same launches per tile, same pixels.
+  DevBuf<uint32_t> tileCostPre;
+  DevBuf<int32_t> splitMap;             // cheap tiles in launch order, then the heavy ones
+  int nPreCheap = 0, nPreHeavy = 0;
+  int prepassSplit = 1;
+  bool preMeasured = false;             // the cost frame had surfaces (tileCostPre is valid)
   std::vector<int32_t> baseMap, curMap; // static launch order (tile_order) / the order in use
   int feedback = 1;                     // option tile_feedback
   int statsMode = 1;                    // option stats_mode: what exa_hip_render_stats collects (1 work counters, 2 wave time by phase)
@@ -423,6 +433,8 @@ struct ExaHipRenderer {
     }
     HIP_TRY(this, tileMap.upload(map.data(), map.size()));
     HIP_TRY(this, tileCost.alloc(size_t(tilesX) * tilesY));
+    HIP_TRY(this, tileCostPre.alloc(size_t(tilesX) * tilesY));
+    nPreCheap = nPreHeavy = 0;
     baseMap = map; curMap = map;
     costPhase = 1;
     nNormal = nWide4 = nWide2 = 0;
@@ -467,6 +479,27 @@ struct ExaHipRenderer {
     if (order != curMap) {
       HIP_TRY(this, hipMemcpy(tileMap.p, order.data(), n * sizeof(int32_t), hipMemcpyHostToDevice));
       curMap.swap(order);
+    }
+    nPreCheap = nPreHeavy = 0;
+    if (preMeasured && prepassSplit) {
+      std::vector<uint32_t> pre(size_t(tilesX) * tilesY, 0);
+      HIP_TRY(this, hipMemcpy(pre.data(), tileCostPre.p, pre.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      uint32_t maxP = 0;
+      for (size_t b = 0; b < n; b++) maxP = std::max(maxP, pre[curMap[b]]);
+      // heavy: a longest iso march above an eighth of the frame's longest (and long enough to matter at all)
+      const uint32_t thr = std::max<uint32_t>(64u, maxP / 8u);
+      std::vector<int32_t> cheap, heavy;
+      for (size_t b = 0; b < n; b++) (pre[curMap[b]] > thr ? heavy : cheap).push_back(curMap[b]);
+      if (!heavy.empty() && !cheap.empty()) {
+        // the heavy pipeline starts with its longest pre-pass rays
+        std::stable_sort(heavy.begin(), heavy.end(), [&](int32_t x, int32_t y) { return pre[x] > pre[y]; });
+        std::vector<int32_t> both(cheap);
+        both.insert(both.end(), heavy.begin(), heavy.end());
+        HIP_TRY(this, splitMap.refill(both.data(), both.size()));
+        nPreCheap = (int)cheap.size(); nPreHeavy = (int)heavy.size();
+      }
+      if (std::getenv("EXA_HIP_VERBOSE"))
+        std::fprintf(stderr, "[exa_hip] pre-pass costs: longest iso march %u steps; %d tiles in the heavy pipeline, %d in the other\n", maxP, nPreHeavy, nPreCheap);
     }
     return assignWide(&costOfTile);
   }
@@ -782,9 +815,15 @@ struct ExaHipRenderer {
       a.walkProbe = walkProbe.p;
     }
     a.tileCost = nullptr;
+    a.tileCostPre = nullptr;
     if (feedback && costPhase == 1 && useKd() && measureCosts) {
       HIP_TRY(this, hipMemsetAsync(tileCost.p, 0, tileCost.n * sizeof(uint32_t), s));
       a.tileCost = tileCost.p;
+      preMeasured = surfacesEnabled();
+      if (preMeasured) {
+        HIP_TRY(this, hipMemsetAsync(tileCostPre.p, 0, tileCostPre.n * sizeof(uint32_t), s));
+        a.tileCostPre = tileCostPre.p;
+      }
     }
     a.kdNodes = kdNodes.p;
     // the instrumented counters re-check every leaf against its region record, so they walk the tree with region ids
@@ -818,8 +857,27 @@ struct ExaHipRenderer {
     HIP_TRY(this, hipEventRecord(ev0, s));
     if (useKd()) {
       const bool surfOn = surfacesEnabled();
-      if (surfOn) HIP_TRY(this, launchSurfacePrepassKd(a, numBlocks, stats, s));
       const bool wide = !stats && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
+      const bool split = surfOn && !stats && !wide && costPhase == 0 && !a.tileCost && nPreHeavy > 0 && nPreCheap > 0
+                         && nPreHeavy + nPreCheap == numBlocks && a.debugPixel < 0;
+      if (split) {
+        // two pipelines side by side (see prepassSplit): pre-pass + march of the heavy tiles, pre-pass + march of the rest
+        HIP_TRY(this, hipEventRecord(evFork, s));
+        RenderArgs ah = a, ac = a;
+        ac.tileMap = splitMap.p;
+        ah.tileMap = splitMap.p + nPreCheap;
+        HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
+        HIP_TRY(this, launchSurfacePrepassKd(ah, nPreHeavy, false, side2));
+        HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
+        HIP_TRY(this, launchSurfacePrepassKd(ac, nPreCheap, false, sideN));
+        HIP_TRY(this, launchRenderKd(ac, nPreCheap, p.gradientShadingDVR != 0, fastMath != 0, true, 0, sideN));
+        HIP_TRY(this, hipEventRecord(evJoinN, sideN));
+        HIP_TRY(this, launchRenderKd(ah, nPreHeavy, p.gradientShadingDVR != 0, fastMath != 0, true, 0, side2));
+        HIP_TRY(this, hipEventRecord(evJoin2, side2));
+        HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
+        HIP_TRY(this, hipStreamWaitEvent(s, evJoinN, 0));
+      } else {
+      if (surfOn) HIP_TRY(this, launchSurfacePrepassKd(a, numBlocks, stats, s));
       if (!wide) {
         HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats ? statsMode : 0, s));
       } else {
@@ -850,6 +908,7 @@ struct ExaHipRenderer {
         if (nWide4) HIP_TRY(this, hipStreamWaitEvent(s, evJoin4, 0));
         if (nWide2) HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
         HIP_TRY(this, hipStreamWaitEvent(s, evJoinN, 0));
+      }
       }
     }
     else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, surfacesEnabled(), stats, s));
@@ -1426,6 +1485,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     if (value != 1 && value != 2) { h->fail("exa_hip_set_option: stats_mode is 1 or 2"); return 1; }
     h->statsMode = value; return 0;
   }
+  if (!std::strcmp(key, "prepass_split")) { h->prepassSplit = value != 0; h->costPhase = 1; return 0; }
   if (!std::strcmp(key, "walk_probe")) { h->walkProbeOn = value != 0; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
