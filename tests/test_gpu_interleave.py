@@ -98,3 +98,23 @@ def test_brick_order_in_memory_does_not_change_the_frame(nf):
     R.setOption("brick_order", 0)
     assert np.array_equal(R.render(), lb)
     R.close()
+
+
+def test_prepass_split_launch_plan_does_not_change_the_frame():
+    """option prepass_split: heavy pre-pass tiles in their own pre-pass + march pipeline beside the rest of the frame"""
+    sc = scenes.config("c3_gear", scale=0.2)
+    kw = dict(W=320, H=256, grad=1, iso=[(0.5, 0)], ao=1, ao_length=200.0, xf_domains=[(0.0, 1.0)] * len(sc.fields))
+    outs = {}
+    for split in (0, 1):
+        case = Case(sc, **kw)
+        case.options = dict(prepass_split=split)
+        R = case.hip_renderer()
+        frames = []
+        for f in range(4):                       # frame 0 measures the costs, the later ones run the plan
+            R.updateFrameID(f)
+            frames.append(R.render().copy())
+        outs[split] = (frames, R.readAccum().copy())
+        R.close()
+    for f in range(4):
+        assert np.array_equal(outs[0][0][f], outs[1][0][f]), f
+    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
