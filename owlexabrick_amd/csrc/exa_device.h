@@ -39,9 +39,9 @@
 #define EXA_IL34_WAVES 4       // ... and with three or four (their cell values and sums need the registers)
 #endif
 #ifndef EXA_PREPASS_ISO_WAVES
-#define EXA_PREPASS_ISO_WAVES 3 // ... and its variant for frames whose only surfaces are implicit iso-surfaces: bound by the latency of its
-                                // longest rays, not by throughput (C3: 3 / 4 / 5 waves 21.08 / 21.07 / 21.62 ms per frame), so it takes
-                                // the registers that keep a one-brick region's march header across the segment
+#define EXA_PREPASS_ISO_WAVES 4 // ... and its variant for frames whose only surfaces are implicit iso-surfaces (125 VGPRs, no scratch).
+                                // C3 is bound by the latency of its longest rays there (3 / 4 / 5 waves: 21.08 / 21.07 / 21.62 ms per frame),
+                                // C5 by throughput (3 waves + the march header kept in registers across a one-brick segment: 13.9 instead of 10.9 ms)
 #endif
 #ifndef EXA_OPT_MED3
 #define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)

@@ -1055,20 +1055,15 @@ __device__ void traceStreamlines(Ctx<STATS> &C, const Ray &ray, SurfaceHit &prd)
 }
 
 // exabrick.cu:1187-1256 isoIntegrateBrick
-template <int STATS, bool CACHE_HDR = false>
+template <int STATS>
 __device__ void isoIntegrateBrick(Ctx<STATS> &C, IsoLast &last, IsoResult &ir, float off,
                                   const Ray &ray, const RegionInfo &ri, float t0, float t1, int numChannels, const bool hitOnly = false)
 {
   unsigned isoChannelMask = 0;
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++)
     if (C.a->fs.iso[i].enabled) isoChannelMask |= 1u << (C.a->fs.iso[i].channel & 31);
-  // A region of one brick (most of them) keeps its march header in registers for the whole segment: the pre-pass is bound
-  // by the LATENCY of its longest rays' dependent steps (on C3 it issues 0.3 G vector instructions in 3.6 ms), and the
-  // header load in front of every sample's cell loads was one of the two dependent memory round trips of a step
-  // (CACHE_HDR: the iso-only pre-pass; with the mesh / contour / streamline code around it the eight registers spill)
-  const bool oneBrick = CACHE_HDR && C.fastSampler && ri.listSize == 1;
-  int4 hdr0 = make_int4(0, 0, 0, 0), hdr1 = make_int4(1, 1, 1, 0);
-  if (oneBrick) { hdr0 = C.a->sc.leafHdr[2u * (unsigned)ri.listBegin]; hdr1 = C.a->sc.leafHdr[2u * (unsigned)ri.listBegin + 1u]; }
+  // (keeping a one-brick region's march header in registers across the segment was measured: the eight registers cost
+  // the iso-only pre-pass its fourth wave per SIMD — C3 3.6 -> 4.0 ms, C5 10.9 -> 13.9 ms — and spill in the generic one)
   const float dt = C.a->p.dt * ri.finestLevelCellWidth;
   float t_i = firstSampleT(t0, dt, off);
   float t_last = t0;
@@ -1091,16 +1086,7 @@ __device__ void isoIntegrateBrick(Ctx<STATS> &C, IsoLast &last, IsoResult &ir, f
       // The reference samples with the derivative here when gradientShadingISO is on (:1224-1231), but the functor never
       // looks at it (:1019-1110 takes the gradient from its own re-sampling at the crossing point): value and validity
       // are the same sums either way, so the step samples are taken without the derivative sums
-      bool doIntegrate;
-      if (oneBrick) {
-        Basis B;
-        B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
-        addBasisFast<false, STATS, false>(C, B, hdr0, hdr1, C.a->sc.scalars + C.a->sc.channelOffset[c], pos);
-        doIntegrate = B.sumW > 1e-20f;                                   // samplePoint (:800-806)
-        if (doIntegrate) cellValue = B.sumWV / B.sumW;
-      } else {
-        doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
-      }
+      const bool doIntegrate = samplePoint<false, STATS>(C, cellValue, grad, ri, pos, c);
       if (doIntegrate) {
         isoFunc(C, last.lastT(c), last.lastV(c), ray, ir, t_sample, cellValue, ri, c, hitOnly);
         last.set(c, t_sample, cellValue);
@@ -1528,7 +1514,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
 // exabrick.cu:1408-1460 traceIsoRay on the kd walk (iso activity bits): segments come out of the
 // ordered walk, one lane at a time refills its own queue here (the iso pre-pass is not the
 // headline path), the march is isoIntegrateBrick.
-template <int STATS, bool CACHE_HDR = false>
+template <int STATS>
 __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *stackF, int *qRegion, float *qT, const bool hitOnly = false)
 {
   const RenderArgs &a = *C.a;
@@ -1579,7 +1565,7 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
     IsoResult ir;
     ir.pixelColor.x = ir.pixelColor.y = ir.pixelColor.z = ir.pixelColor.w = 0.f;
     ir.t_hit = -1.f; ir.gradient = mk(0.f, 0.f, 0.f);
-    isoIntegrateBrick<STATS, CACHE_HDR>(C, last, ir, off, ray, ri, t0, t1, a.p.numPrimaryChannels, hitOnly);
+    isoIntegrateBrick(C, last, ir, off, ray, ri, t0, t1, a.p.numPrimaryChannels, hitOnly);
     if (ir.t_hit >= 0.f) {
       result.primID = EXA_PRIMID_ISOSURFACE;
       result.t_hit = ir.t_hit / dt_scale;
@@ -1639,7 +1625,7 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
   for (int i = 0; i < EXA_MAX_ISO_SURFACES; i++) activeIso |= (C.a->fs.iso[i].enabled != 0);
   if (activeIso) {
     // the rays traced without contour planes are the ambient-occlusion rays (:1638): only hit / no hit is read
-    const SurfaceHit isoPRD = traceIsoRayKd<STATS, ISO_ONLY>(C, ray, 0.f, stackF, qRegion, qT, !withContourPlanes);
+    const SurfaceHit isoPRD = traceIsoRayKd(C, ray, 0.f, stackF, qRegion, qT, !withContourPlanes);
     if (isoPRD.primID == EXA_PRIMID_ISOSURFACE && isoPRD.t_hit < prd.t_hit) prd = isoPRD;
   }
 }

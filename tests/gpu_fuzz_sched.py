@@ -2,7 +2,8 @@
     python tests/gpu_fuzz_sched.py FIRST LAST [--keep-going]
 A case of tests/fuzz_cases.py at a frame of 8..60 tiles, rendered (2 accumulated frames) with the defaults, then again
 with a random launch order, with the cost feedback in its three phases, with every tile on the wide march (2 and 4 lanes
-per ray; one primary channel only), as the shards of a random number of ranks re-assembled by the device untile kernel
+per ray; one primary channel only), with the memory layouts and launch plans of round 3 toggled (brick order, channel
+interleaving, 64-bit addresses, the split pre-pass plan), as the shards of a random number of ranks re-assembled by the device untile kernel
 and by its host mirror, and through a multi-device handle: every one must give the same RGBA8 frame and the same
 accumulation buffer bit for bit."""
 import sys
@@ -54,6 +55,13 @@ def check(seed):
             if not _same(_frames(R), base):
                 bad.append(f"wide_march {lanes}")
         R.setOption("wide_march", 1)
+    # round 3: where the cells lie in memory and how a frame with surfaces is launched
+    for key, val in (("brick_order", 1), ("interleave", 0), ("addr64", 1), ("prepass_split", 0), ("brick_order", 0), ("interleave", 1),
+                     ("prepass_split", 1), ("addr64", 0)):
+        R.setOption(key, val)
+        for k in range(2 if key == "prepass_split" else 1):      # the plan changes after its measuring frame
+            if not _same(_frames(R), base):
+                bad.append(f"{key}={val} (pass {k})")
     R.close()
     # shards of a random world, re-assembled
     world = int(rng.choice([2, 3, 5, 8, 13]))

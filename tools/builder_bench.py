@@ -50,11 +50,22 @@ def expand_cells(scene):
 
 
 def run(cmd, **kw):
+    """run to completion; a heartbeat line on stderr every minute (a long exaBuilder run must not look hung)"""
+    import tempfile
     t = time.time()
-    out = subprocess.run(cmd, capture_output=True, text=True, **kw)
-    if out.returncode:
-        raise SystemExit(f"{' '.join(cmd)} failed:\n{out.stdout}\n{out.stderr}")
-    return out.stdout, time.time() - t
+    with tempfile.TemporaryFile("w+") as fo, tempfile.TemporaryFile("w+") as fe:
+        p = subprocess.Popen(cmd, stdout=fo, stderr=fe, text=True, **kw)
+        while True:
+            try:
+                p.wait(timeout=60)
+                break
+            except subprocess.TimeoutExpired:
+                print(f"[builder_bench] {os.path.basename(cmd[0])} running, {time.time() - t:.0f}s", file=sys.stderr, flush=True)
+        fo.seek(0); fe.seek(0)
+        out, err = fo.read(), fe.read()
+    if p.returncode:
+        raise SystemExit(f"{' '.join(cmd)} failed:\n{out}\n{err}")
+    return out, time.time() - t
 
 
 def render(cfg, size, frames):
@@ -83,10 +94,14 @@ def main():
     sc = scenes.config("c4_exajet", scale=args.scale)
     res = {"scene": f"c4_exajet scale {args.scale}", "size": args.size, "frames": args.frames}
     # (1) the generator's 8^3 bricks, through the on-disk formats
+    print(f"[builder_bench] scene: {sc.num_cells} cells, {sc.bricks7.shape[0]} bricks", file=sys.stderr, flush=True)
     cfg8 = scenes.write_exa(sc, args.out, name="gen8")
+    print("[builder_bench] gen8 written", file=sys.stderr, flush=True)
     res["generator_8cubed_bricks"] = render(cfg8, args.size, args.frames)
     # (2) the same cells through exaBuilder
+    print("[builder_bench] gen8 rendered; expanding cells", file=sys.stderr, flush=True)
     cells, scal = expand_cells(sc)
+    print("[builder_bench] cells expanded; writing + exaBuilder", file=sys.stderr, flush=True)
     cells.tofile(os.path.join(args.out, "built.cells"))
     scal.tofile(os.path.join(args.out, "built_0.scalars"))
     _, t_build = run([os.path.join(HOST, "exaBuilder"), os.path.join(args.out, "built.cells"), "-o",
