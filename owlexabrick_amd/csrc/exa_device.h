@@ -131,6 +131,11 @@ enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CO
                 ST_T_BRICK, ST_T_FINAL, ST_T_WALK, ST_T_SEG, ST_T_OTHER,
                 ST_RESTARTS, ST_UNION, ST_PROBE_OVERFLOW, ST_COUNT };
 
+// a shaded surface hit whose ambient-occlusion rays aoRaysKdKernel traces: hit point + |cos| of the primary ray, normal +
+// ambient term, base colour + the LCG state its two samples draw from, pixel slot
+struct alignas(16) AoRecord { float4 posFd, ngAmb, baseRnd; uint32_t slot, pad0, pad1, pad2; };
+static_assert(sizeof(AoRecord) == 64, "AO record = four 16-byte stores");
+
 struct RenderArgs {
   DeviceScene        sc;
   const BvhNode     *volNodes;
@@ -182,6 +187,8 @@ struct RenderArgs {
   const int32_t     *wideTileMap;   // wide march: launch slot / L -> global tile id
   float4            *wideSegs;      // wide march: [tile of this launch][ray][window][kWideSegCap] {record, tn, tf, -}
   uint32_t          *walkProbe;     // != null (counting variant, option walk_probe): per wave a hash set of kWalkProbeSize node ids
+  AoRecord          *aoRecs;        // surfaces pre-pass -> AO kernel: one record per shaded hit (NULL: AO rays traced inline)
+  uint32_t          *aoCount;       // surfaces pre-pass -> AO kernel: number of listed hits (cleared before the pre-pass)
   uint32_t          *tileCostPre;   // != null: per tile id, steps of the longest iso march of the surfaces pre-pass
   uint32_t          *tileCost;      // != null: per tile id, brick visits of the tile's longest ray (launch-order feedback)
 };

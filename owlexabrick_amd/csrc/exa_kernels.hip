@@ -1637,7 +1637,11 @@ __device__ __forceinline__ void traceSurfacesKd(Ctx<STATS> &C, const Ray &ray, S
 // to it through a[].surf / surfRnd: the generic surface code needs ~130 VGPRs, the march 80, and one
 // fused kernel would run the march at half its occupancy.
 // ------------------------------------------------------------------------
-template <int STATS, bool ISO_ONLY>
+// AO_DEFER: the ambient-occlusion rays of a shaded hit (:1611-1645) are not traced here, lane by lane behind the primary
+// ray with the lanes that hit nothing waiting, but handed to aoRaysKdKernel below as a compact list (one record per shaded
+// hit, appended with one atomic per wave): there every lane traces one AO ray.  Same rays, same random numbers, same
+// pixel arithmetic; only which lane of which launch traces a ray changes.  (The counting variant keeps them inline.)
+template <int STATS, bool ISO_ONLY, bool AO_DEFER>
 __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_PREPASS_WAVES)) void surfacePrepassKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1686,6 +1690,8 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
     // ---- surfaces first: implicit iso-surface hit, AO rays, background colour (:1601-1652) ----
     V3 bgColor = mk(0.f, 0.f, 0.f);
     float surface_t_hit = ray.tmax;
+    bool deferAo = false;
+    AoRecord rec;
     {
       SurfaceHit surface;
       traceSurfacesKd<STATS, ISO_ONLY>(C, ray, surface, true, stackF, qRegion, qT);
@@ -1694,9 +1700,18 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
           || surface.primID == EXA_PRIMID_STREAMLINE) {
         const bool shade = surface.primID >= 0 || surface.primID == EXA_PRIMID_PLANE || surface.primID == EXA_PRIMID_STREAMLINE
                         || (surface.primID == EXA_PRIMID_ISOSURFACE && a.p.gradientShadingISO);
-        if (shade && length(surface.Ng) > 0.f) {
+        if (AO_DEFER && shade && length(surface.Ng) > 0.f && fs.ao.enabled) {
+          // record for aoRaysKdKernel: hit point, |cos| of the primary ray, normal, colour, and the LCG state from which
+          // the two samples draw (u1, u2 each, :1624-1625); this pixel's state moves past those four draws
+          const V3 isect_pos = ray.org + surface.t_hit * ray.dir;
+          rec.posFd = make_float4(isect_pos.x, isect_pos.y, isect_pos.z, fabsf(dot(ray.dir, surface.Ng)));
+          rec.ngAmb = make_float4(surface.Ng.x, surface.Ng.y, surface.Ng.z, surface.ambient);
+          rec.baseRnd = make_float4(surface.baseColor.x, surface.baseColor.y, surface.baseColor.z, __uint_as_float(rnd.state));
+          rnd.next(); rnd.next(); rnd.next(); rnd.next();
+          deferAo = true;
+        } else if (shade && length(surface.Ng) > 0.f) {
           const float AO_Radius = fs.ao.length;
-          const int AO_Samples = fs.ao.enabled ? 2 : 0;
+          const int AO_Samples = (!AO_DEFER && fs.ao.enabled) ? 2 : 0;     // AO_DEFER: only hits without AO get here
           const V3 isect_pos = ray.org + surface.t_hit * ray.dir;
           const V3 wN = surface.Ng;
           const V3 vN = fabsf(wN.x) > fabsf(wN.y) ? normalize(mk(-wN.z, 0.f, wN.x)) : normalize(mk(0.f, wN.z, -wN.y));
@@ -1716,7 +1731,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
             if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE
                 || ao.primID == EXA_PRIMID_STREAMLINE) hitCnt++;
           }
-          const float shadow = fs.ao.enabled ? (float)hitCnt / AO_Samples : 0.f;
+          const float shadow = (!AO_DEFER && fs.ao.enabled) ? (float)hitCnt / AO_Samples : 0.f;
           const float fd = fabsf(dot(ray.dir, surface.Ng));
           const float ns = 1.f - shadow;
           bgColor = mk(surface.ambient + surface.baseColor.x * fd * ns,
@@ -1731,6 +1746,21 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
                                        : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
     a.surf[slot] = make_float4(bgColor.x, bgColor.y, bgColor.z, surface_t_hit);
     a.surfRnd[slot] = rnd.state;
+    if (AO_DEFER) {
+      // append: one atomicAdd per wave (ballot + prefix count), 64 B per record
+      const unsigned long long m = __ballot(deferAo);
+      if (m) {
+        const int lane_ = threadIdx.x & 63;
+        const int leader = __ffsll((long long)m) - 1;
+        unsigned base = 0;
+        if (lane_ == leader) base = atomicAdd(a.aoCount, (unsigned)__popcll(m));
+        base = (unsigned)__shfl((int)base, leader, 64);
+        if (deferAo) {
+          rec.slot = (uint32_t)slot; rec.pad0 = rec.pad1 = rec.pad2 = 0;
+          a.aoRecs[base + (unsigned)__popcll(m & ((1ull << lane_) - 1ull))] = rec;
+        }
+      }
+    }
   }
 
   if (a.tileCostPre) {
@@ -1747,6 +1777,72 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
       if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.stats[i], v);
     }
   }
+}
+
+// The ambient-occlusion rays of the hits surfacePrepassKdKernel<.., AO_DEFER> listed (exabrick.cu:1611-1652): lane 2h + i
+// traces sample i of hit h — the cosine-distributed direction from the hit's own LCG draws (:85-94, :1624-1633), the trace
+// through the surfaces without contour planes (:1638), hit or no hit — and the two lanes of a hit combine into the shadow
+// term and the hit's background colour (:1647-1650), which replaces the placeholder in a.surf.
+template <bool ISO_ONLY>
+__global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? 5 : EXA_PREPASS_WAVES)) void aoRaysKdKernel(const RenderArgs a)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *xfLds = reinterpret_cast<float4 *>(smem);
+  unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
+  int *stackRef = reinterpret_cast<int *>(sp0);
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
+  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
+  __syncthreads();
+  Ctx<0> C;
+  C.a = &a;
+  C.xfLds = xfLds;
+  C.stack = stackRef + threadIdx.x;
+  C.guardTripped = false;
+  C.fastSampler = a.fastSampler != 0;
+  const ExaHipFrameState &fs = a.fs;
+  const unsigned numRays = 2u * *a.aoCount;
+  // a fixed grid walks the list (its length is only known on the device)
+  for (unsigned base = blockIdx.x * kKdBlock; base < numRays; base += gridDim.x * kKdBlock) {
+    const unsigned j = base + threadIdx.x;
+    const bool live = j < numRays;
+    int hitFlag = 0;
+    float4 posFd = make_float4(0.f, 0.f, 0.f, 0.f), ngAmb = posFd, baseRnd = posFd;
+    uint32_t slot = 0;
+    if (live) {
+      const AoRecord *r = a.aoRecs + (j >> 1);
+      posFd = r->posFd; ngAmb = r->ngAmb; baseRnd = r->baseRnd; slot = r->slot;
+      Lcg rnd;
+      rnd.state = __float_as_uint(baseRnd.w);
+      if (j & 1u) { rnd.next(); rnd.next(); }                       // the second sample's draws follow the first's
+      const V3 wN = mk(ngAmb.x, ngAmb.y, ngAmb.z);
+      const V3 vN = fabsf(wN.x) > fabsf(wN.y) ? normalize(mk(-wN.z, 0.f, wN.x)) : normalize(mk(0.f, wN.z, -wN.y));
+      const V3 uN = cross(vN, wN);
+      const float u1 = rnd.next(), u2 = rnd.next();
+      const float rr = sqrtf(u1);
+      const float theta = 2.f * 3.14159265358979323846f * u2;
+      const V3 sp = mk(rr * cosf(theta), rr * sinf(theta), sqrtf(1.f - u1));
+      Ray ao_ray;
+      ao_ray.org = mk(posFd.x, posFd.y, posFd.z);
+      ao_ray.dir = normalize((sp.x * uN + sp.y * vN) + sp.z * wN);
+      ao_ray.tmin = 1e-4f; ao_ray.tmax = fs.ao.length;
+      SurfaceHit ao;
+      traceSurfacesKd<0, ISO_ONLY>(C, ao_ray, ao, false, stackF, qRegion, qT);
+      if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE
+          || ao.primID == EXA_PRIMID_STREAMLINE) hitFlag = 1;
+    }
+    const int other = __shfl_xor(hitFlag, 1, 64);                    // the hit's other sample: the neighbouring lane
+    if (live && !(j & 1u)) {
+      const int hitCnt = hitFlag + other;
+      const float shadow = (float)hitCnt / 2;                         // AO_Samples = 2 (:1613)
+      const float fd = posFd.w;
+      const float ns = 1.f - shadow;
+      const float t_hit = a.surf[slot].w;
+      a.surf[slot] = make_float4(ngAmb.w + baseRnd.x * fd * ns, ngAmb.w + baseRnd.y * fd * ns, ngAmb.w + baseRnd.z * fd * ns, t_hit);
+    }
+  }
+  if (C.guardTripped) atomicExch(a.errorFlag, 1);
 }
 
 // MULTI: 0 = one primary channel; 1 = several, at most two TF tables in LDS (the 6-workgroup layout below); 2 = several, more tables
@@ -2444,9 +2540,20 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   bool isoOnly = a.numTris == 0 && a.numStreamPrims == 0;
   for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; i++) isoOnly = isoOnly && !a.fs.contour[i].enabled;
-  if (stats)        hipLaunchKernelGGL((surfacePrepassKdKernel<1, false>), grid, block, lds, s, a);
-  else if (isoOnly) hipLaunchKernelGGL((surfacePrepassKdKernel<0, true>), grid, block, lds, s, a);
-  else              hipLaunchKernelGGL((surfacePrepassKdKernel<0, false>), grid, block, lds, s, a);
+  // the shipped variants hand their AO rays to aoRaysKdKernel (a.aoRecs / a.aoCount, cleared by the caller)
+  const bool defer = !stats && a.aoRecs && a.aoCount;
+  if (stats)        hipLaunchKernelGGL((surfacePrepassKdKernel<1, false, false>), grid, block, lds, s, a);
+  else if (isoOnly) { if (defer) hipLaunchKernelGGL((surfacePrepassKdKernel<0, true, true>), grid, block, lds, s, a);
+                      else       hipLaunchKernelGGL((surfacePrepassKdKernel<0, true, false>), grid, block, lds, s, a); }
+  else              { if (defer) hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, true>), grid, block, lds, s, a);
+                      else       hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, false>), grid, block, lds, s, a); }
+  if (defer && a.fs.ao.enabled) {
+    const int maxBlocks = 256 * 8;                                   // the list's length is on the device: a fixed grid walks it
+    const long long upper = ((long long)numBlocks * kTilePixels * 2 + kKdBlock - 1) / kKdBlock;
+    const dim3 g2((unsigned)(upper < maxBlocks ? upper : maxBlocks));
+    if (isoOnly) hipLaunchKernelGGL((aoRaysKdKernel<true>), g2, block, lds, s, a);
+    else         hipLaunchKernelGGL((aoRaysKdKernel<false>), g2, block, lds, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -329,6 +329,9 @@ struct ExaHipRenderer {
   hipStream_t side4 = nullptr, side2 = nullptr, sideN = nullptr;
   hipEvent_t evFork = nullptr, evJoin4 = nullptr, evJoin2 = nullptr, evJoinN = nullptr;
   DevBuf<uint32_t> surfRnd;
+  DevBuf<AoRecord> aoRecs;              // deferred AO rays: one record per shaded hit and pixel slot at most
+  DevBuf<uint32_t> aoCount;             // [0] the frame's list (or the cheap pipeline's), [1] the heavy pipeline's
+  int aoDefer = 1;                      // option ao_defer
   DevBuf<uint32_t> color;
   DevBuf<int32_t> tileMap;
   int numBlocks = 0;
@@ -854,6 +857,13 @@ struct ExaHipRenderer {
       HIP_TRY(this, surfRnd.alloc(accum.n));
       a.surf = surf.p; a.surfRnd = surfRnd.p;
     }
+    a.aoRecs = nullptr; a.aoCount = nullptr;
+    if (useKd() && surfacesEnabled() && fs.ao.enabled && aoDefer && !stats) {
+      if (aoRecs.n != accum.n) HIP_TRY(this, aoRecs.alloc(accum.n));
+      if (!aoCount.p) HIP_TRY(this, aoCount.alloc(2));
+      HIP_TRY(this, hipMemsetAsync(aoCount.p, 0, 2 * sizeof(uint32_t), s));
+      a.aoRecs = aoRecs.p; a.aoCount = aoCount.p;
+    }
     HIP_TRY(this, hipEventRecord(ev0, s));
     if (useKd()) {
       const bool surfOn = surfacesEnabled();
@@ -866,6 +876,10 @@ struct ExaHipRenderer {
         RenderArgs ah = a, ac = a;
         ac.tileMap = splitMap.p;
         ah.tileMap = splitMap.p + nPreCheap;
+        if (a.aoRecs) {                                   // each pipeline appends to its own list
+          ah.aoRecs = a.aoRecs + size_t(nPreCheap) * kTilePixels;
+          ah.aoCount = a.aoCount + 1;
+        }
         HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
         HIP_TRY(this, launchSurfacePrepassKd(ah, nPreHeavy, false, side2));
         HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
@@ -1485,6 +1499,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     if (value != 1 && value != 2) { h->fail("exa_hip_set_option: stats_mode is 1 or 2"); return 1; }
     h->statsMode = value; return 0;
   }
+  if (!std::strcmp(key, "ao_defer")) { h->aoDefer = value != 0; return 0; }
   if (!std::strcmp(key, "prepass_split")) { h->prepassSplit = value != 0; h->costPhase = 1; return 0; }
   if (!std::strcmp(key, "walk_probe")) { h->walkProbeOn = value != 0; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }

@@ -105,9 +105,9 @@ def test_prepass_split_launch_plan_does_not_change_the_frame():
     sc = scenes.config("c3_gear", scale=0.2)
     kw = dict(W=320, H=256, grad=1, iso=[(0.5, 0)], ao=1, ao_length=200.0, xf_domains=[(0.0, 1.0)] * len(sc.fields))
     outs = {}
-    for split in (0, 1):
+    for split in (0, 1, 2):                      # 2: the split plan with the AO rays traced inline
         case = Case(sc, **kw)
-        case.options = dict(prepass_split=split)
+        case.options = dict(prepass_split=min(split, 1), ao_defer=0 if split in (0, 2) else 1)
         R = case.hip_renderer()
         frames = []
         for f in range(4):                       # frame 0 measures the costs, the later ones run the plan
@@ -115,6 +115,33 @@ def test_prepass_split_launch_plan_does_not_change_the_frame():
             frames.append(R.render().copy())
         outs[split] = (frames, R.readAccum().copy())
         R.close()
-    for f in range(4):
-        assert np.array_equal(outs[0][0][f], outs[1][0][f]), f
-    assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+    for k in (1, 2):
+        for f in range(4):
+            assert np.array_equal(outs[0][0][f], outs[k][0][f]), (k, f)
+        assert np.array_equal(outs[0][1].view(np.uint32), outs[k][1].view(np.uint32)), k
+
+
+@pytest.mark.parametrize("world", [1, 3])
+def test_deferred_ao_rays_equal_inline_ao_rays(world):
+    """option ao_defer: the AO rays of the shaded hits traced by their own launch over a compact hit list — with a mesh in
+    the scene (generic pre-pass), ragged tiles, several accumulated frames and a sharded handle"""
+    sc = _scene(2, seed=11)
+    lo, hi = sc.bounds()
+    c = 0.5 * (lo + hi)
+    tri = (np.array([[c[0] - 9, c[1] - 7, c[2]], [c[0] + 11, c[1] - 5, c[2] + 3], [c[0], c[1] + 12, c[2] - 2]], dtype=np.float32),
+           np.array([[0, 1, 2]], dtype=np.int32))
+    for meshes in (None, [tri]):
+        kw = dict(W=104, H=72, grad=1, iso=[(0.42, 0), (0.5, 1)], ao=1, ao_length=30.0, meshes=meshes)
+        outs = []
+        for defer in (0, 1):
+            case = Case(sc, **kw)
+            case.options = dict(ao_defer=defer)
+            R = case.hip_renderer()
+            R.setShard(world - 1, world)
+            for f in range(3):
+                R.updateFrameID(f)
+                img = R.render().copy()
+            outs.append((img, R.readAccum().copy()))
+            R.close()
+        assert np.array_equal(outs[0][0], outs[1][0])
+        assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
