@@ -34,6 +34,13 @@ GOLDEN_CASES = {
     "ex4_grad_iso2": ("ex4", dict(W=64, H=48, grad=1, iso=[(0.3, 0), (0.7, 0)])),
     "ex4_accum3": ("ex4", dict(W=64, H=48, grad=1, frames=3)),
     "ex3_contour_iso": ("ex3", dict(W=64, H=48, grad=1, iso=[(0.6, 0)], contour=[([1, 1, 0.2], 0.55, 0)], opacity_scale=0.2)),
+    # The full-precision TF filter weight (option tf_filter = 0).  These four files are the goldens as they were BEFORE the
+    # 1.8 fixed-point weight became the default (commit c1b5d4e~1, taken from the history, not regenerated): the oracle and
+    # the kernels in that mode still give them bit for bit, i.e. the change of default did not move the old path.
+    "ex3_grad_tf0": ("ex3", dict(W=64, H=48, grad=1, tf_filter=0)),
+    "ex4_dvr_band_tf0": ("ex4", dict(W=64, H=48, xf="band", tf_filter=0)),
+    "ex2_grad_iso_tf0": ("ex2", dict(W=48, H=32, grad=1, iso=[(0.2, 0)], tf_filter=0)),
+    "ex4_accum3_tf0": ("ex4", dict(W=64, H=48, grad=1, frames=3, tf_filter=0)),
     # BASELINE.json configs[0]: 64^3 single-level brick with the ex2 corner pattern, 512x512, viewer
     # default camera / TF / dt, gradient shading off and on; the fixture holds the centre 192x192 crop of the frame
     "c1_64_512": ("c1_64", dict(W=512, H=512, window=(160, 160, 352, 352))),
