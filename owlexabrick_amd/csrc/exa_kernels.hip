@@ -1802,10 +1802,16 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? 5 : EXA_PREPASS_WAVES)) void 
   C.guardTripped = false;
   C.fastSampler = a.fastSampler != 0;
   const ExaHipFrameState &fs = a.fs;
-  const unsigned numRays = 2u * *a.aoCount;
-  // a fixed grid walks the list (its length is only known on the device)
-  for (unsigned base = blockIdx.x * kKdBlock; base < numRays; base += gridDim.x * kKdBlock) {
-    const unsigned j = base + threadIdx.x;
+  const unsigned numRays = 2u * a.aoCount[0];
+  // The list's length is only known on the device: a grid of resident waves takes chunks of 64 rays from a shared
+  // counter (a.aoCount[2], cleared with the list) until the list is used up — rays differ in length by orders of magnitude,
+  // a static split leaves most of the grid waiting for its slowest part.  Every wave ends: the counter only grows.
+  for (;;) {
+    unsigned base = 0;
+    if ((threadIdx.x & 63) == 0) base = atomicAdd(&a.aoCount[2], 64u);
+    base = (unsigned)__shfl((int)base, 0, 64);
+    if (base >= numRays) break;
+    const unsigned j = base + (threadIdx.x & 63);
     const bool live = j < numRays;
     int hitFlag = 0;
     float4 posFd = make_float4(0.f, 0.f, 0.f, 0.f), ngAmb = posFd, baseRnd = posFd;
@@ -2548,7 +2554,7 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
   else              { if (defer) hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, true>), grid, block, lds, s, a);
                       else       hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, false>), grid, block, lds, s, a); }
   if (defer && a.fs.ao.enabled) {
-    const int maxBlocks = 256 * 8;                                   // the list's length is on the device: a fixed grid walks it
+    const int maxBlocks = 256 * 5;                                   // what the device holds at once (5 workgroups per CU)
     const long long upper = ((long long)numBlocks * kTilePixels * 2 + kKdBlock - 1) / kKdBlock;
     const dim3 g2((unsigned)(upper < maxBlocks ? upper : maxBlocks));
     if (isoOnly) hipLaunchKernelGGL((aoRaysKdKernel<true>), g2, block, lds, s, a);
