@@ -17,9 +17,9 @@ for f in glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.csv"), 
     for (d, c), v in per_dispatch.items():
         acc[names[d]][c].append(v)
 for k in sorted(acc):
-    if "render" not in k:
+    if not any(t in k for t in ("render", "surfacePrepass", "aoRays")):
         continue
-    print("==", k[:90])
+    print("==", k[:110])
     c = {n: sum(v) / len(v) for n, v in acc[k].items()}
     for n in sorted(c):
         print(f"   {n:34s} {c[n]:.6g}   (n={len(acc[k][n])})")
