@@ -2519,6 +2519,274 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
 }
 
+// ------------------------------------------------------------------------
+// Deep march: L = 8 or 16 lanes per ray for the tiles whose longest rays are a frame's critical path (round 3).  The wide
+// march above gains little beyond 4 lanes because its lanes work through ONE segment at a time and a segment holds ~6
+// samples.  Here the L lanes take the next L samples of the RAY, across segment boundaries:
+//   scan      every lane of the ray runs the same short sequential scan over the next L samples — the accept test of the
+//             listed leaves (t0 = max(tmin, tn) < t1, tmin = t1 * 1.0000001f), firstSampleT at a segment start, t_i += dt
+//             inside a segment (a running float sum, exabrick.cu:1141-1166) — and keeps the sample with its own index;
+//   evaluate  each lane reconstructs, shades and opacity-corrects its own sample (its own region: the lanes of a ray may
+//             sit in different segments);
+//   fold      the L samples are composited in order by every lane (identical copies of the pixel), termination at 0.98
+//             checked after each one (:1180).
+// Same samples, same arithmetic, same order as the one-lane march: bit-identical pixels.  Phase 1 (window walkers, one
+// depth window per lane, leaf lists in HBM) is the wide march's.
+// ------------------------------------------------------------------------
+template <int L> struct DeepCap { enum { value = 2048 / L }; };       // listed leaves per window and round
+
+template <bool GRAD, bool FAST, bool SURF, int L, bool SMALL>
+__global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdDeepKernel(const RenderArgs a)
+{
+  constexpr unsigned CAP = DeepCap<L>::value;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float4 *xfLds = reinterpret_cast<float4 *>(smem);
+  unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
+  int *stackRef = reinterpret_cast<int *>(sp0);
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
+  __syncthreads();
+
+  Ctx<false> C;
+  C.a = &a;
+  C.xfLds = xfLds;
+  C.stack = stackRef + threadIdx.x;
+  C.guardTripped = false;
+  const unsigned long long clockBegin = clock64();                              // :1588
+  __builtin_amdgcn_s_setprio(3);
+  // L workgroups per 16x16 tile; a wave marches 64/L rays
+  const int tile = a.wideTileMap[blockIdx.x / L];
+  const int part = blockIdx.x % L;
+  const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+  const int lane = threadIdx.x & 63, sub = lane & (L - 1), lead = lane & ~(L - 1);
+  const bool leader = sub == 0;                        // writes the pixel
+  const int r = part * (kTilePixels / L) + (threadIdx.x >> 6) * (64 / L) + lane / L;     // ray of the tile
+  const int inX = (((r >> 6) & 1) << 3) + (r & 7), inY = ((r >> 7) << 3) + ((r >> 3) & 7);   // 8x8 block order, as the one-lane kernel
+  const int px = tx * kTile + inX, py = ty * kTile + inY;
+  const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
+
+  unsigned myVisits = 0;
+  if (inside) {
+    const ExaHipFrameState &fs = a.fs;
+    const int frameID = fs.frameID;
+    Lcg rnd;
+    rnd.init((uint32_t)(frameID * a.W * a.H) + (uint32_t)px, (uint32_t)py);      // :1591-1592
+    const float sx = float(px) + rnd.next();
+    const float sy = float(py) + rnd.next();
+    Ray ray;
+    ray.org = mk(fs.cam_pos);
+    ray.dir = normalize((mk(fs.cam_dir00) + sx * mk(fs.cam_dirDu)) + sy * mk(fs.cam_dirDv));
+    ray.tmin = 1e-6f; ray.tmax = 1e8f;
+    const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py
+                                       : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+    float surface_t_hit = ray.tmax;
+    if (SURF) {
+      surface_t_hit = a.surf[slot].w;
+      rnd.state = a.surfRnd[slot];
+    }
+    const float interleavedSamplingOffset = rnd.next();                           // :1655
+    ray.tmax = surface_t_hit;                                                     // :1657-1659
+    if (fs.clipBox.enabled) {
+      float c0, c1;
+      boxTest(ray, mk(fs.clipBox.lo), mk(fs.clipBox.hi), c0, c1);
+      ray.tmin = c0; ray.tmax = c1;
+    }
+    surface_t_hit = ray.tmax;
+    ray.org = xfmPoint(fs, ray.org);                                              // :1664-1668
+    ray.dir = xfmVector(fs, ray.dir);
+    const float dt_scale = length(ray.dir);
+    ray.dir = normalize(ray.dir);
+    ray.tmin = dt_scale * ray.tmin;
+    ray.tmax = surface_t_hit * dt_scale;
+
+    Color4 pixelColor; pixelColor.x = pixelColor.y = pixelColor.z = pixelColor.w = 0.f;
+
+    // ---- phase 1: window walkers (as in the wide march) ----
+    float4 *const mySegs = a.wideSegs + (size_t(blockIdx.x / L) * kTilePixels * L + size_t(r) * L + sub) * CAP;
+    unsigned myCount = 0;
+    KdWalk w;
+    w.pk.v = 0;
+    float winLo, winHi;
+    {
+      Ray whole = ray; whole.tmin = -INFINITY; whole.tmax = INFINITY;
+      float r0, r1;
+      const bool hit = boxTest(whole, mk(a.kdLo), mk(a.kdHi), r0, r1);
+      w.tn = fmaxf(r0, ray.tmin);
+      w.tf = fminf(r1, ray.tmax);
+      w.tEnd = w.tf;
+      w.ref = (hit && w.tn < w.tf) ? a.kdMarchRoot : EXA_KD_DONE;
+      const float span = w.tf - w.tn;
+      winLo = sub == 0 ? -INFINITY : w.tn + span * (float(sub) / float(L));
+      winHi = sub == L - 1 ? INFINITY : w.tn + span * (float(sub + 1) / float(L));
+      for (unsigned g = 0;; g++) {
+        if (g == 0xfffffff0u) { C.guardTripped = true; break; }
+        const bool want = w.ref != EXA_KD_DONE && myCount < CAP;
+        if (!anyLane(want)) break;
+        if (want) kdCollectStep(C, w, winLo, winHi, a, stackF, ray, a.kdMarchNodes, a.kdMarchRoot, mySegs, myCount);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- phase 2: scan / evaluate / fold, L samples of the ray per step ----
+    float walkTmin = ray.tmin;
+    int curWin = 0;
+    unsigned curIdx = 0, curCount = (unsigned)__shfl((int)myCount, lead, 64);
+    const float4 *curSegs = a.wideSegs + (size_t(blockIdx.x / L) * kTilePixels * L + size_t(r) * L) * CAP;
+    // scan state: identical in all lanes of the ray
+    bool haveSeg = false, rayEnded = false, rayDone = false;
+    int segRec = 0;
+    float t1 = 0.f, dtSeg = 0.f, t_i = 0.f, t_last = 0.f;
+    const float *field0 = a.sc.scalars + a.sc.channelOffset[0];
+
+    for (unsigned step = 0;; step++) {
+      if (step == 0xfffffff0u) { C.guardTripped = true; break; }
+      // ---- scan: the ray's next L samples, in order ----
+      bool myExists = false;
+      float myTs = 0.f, myDt = 0.f;
+      int myRec = 0, nAvail = 0;
+#pragma unroll 1
+      for (int s_ = 0; s_ < L; s_++) {
+        if (!rayEnded && !haveSeg) {
+          // next segment: the next listed leaf that passes the reference's test against the running tmin
+          // (exabrick.cu:197-210, :1698)
+          for (unsigned g = 0;; g++) {
+            if (g == 0xfffffff0u) { C.guardTripped = true; rayEnded = true; break; }
+            if (curIdx >= curCount) {
+              // list of window curWin used up: another round of its walker if it stopped at a full list (the other
+              // lanes of the ray wait), otherwise on to the next window
+              if (__shfl((int)(w.ref != EXA_KD_DONE), lead + curWin, 64)) {
+                if (sub == curWin) {
+                  myCount = 0;
+                  for (unsigned h = 0; w.ref != EXA_KD_DONE && myCount < CAP; h++) {
+                    if (h == 0xfffffff0u) { C.guardTripped = true; break; }
+                    kdCollectStep(C, w, winLo, winHi, a, stackF, ray, a.kdMarchNodes, a.kdMarchRoot, mySegs, myCount);
+                  }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                curIdx = 0;
+                curCount = (unsigned)__shfl((int)myCount, lead + curWin, 64);
+                continue;
+              }
+              if (++curWin == L) { rayEnded = true; break; }
+              curIdx = 0;
+              curCount = (unsigned)__shfl((int)myCount, lead + curWin, 64);
+              curSegs += CAP;
+              continue;
+            }
+            const float4 e = curSegs[curIdx++];
+            const float t0 = fmaxf(walkTmin, e.y);
+            if (t0 < e.z) {
+              segRec = __float_as_int(e.x);
+              t1 = e.z;
+              walkTmin = t1 * (1.0000001f);
+              float flcw;
+              if (a.leafBeginBits) flcw = __int_as_float((127 + (int)((unsigned)segRec >> (a.leafBeginBits + a.leafSizeBits))) << 23);
+              else flcw = a.sc.regionInfo[segRec].finestLevelCellWidth;
+              dtSeg = a.p.dt * flcw;
+              t_i = firstSampleT(t0, dtSeg, interleavedSamplingOffset);             // :1141-1144
+              t_last = t0;
+              haveSeg = true;
+              break;
+            }
+          }
+        }
+        if (!rayEnded) {
+          const float tn = fminf(t_i, t1);                                          // :1158-1166
+          if (s_ == sub) { myTs = 0.5f * (fminf(t1, tn) + t_last); myDt = tn - t_last; myRec = segRec; myExists = true; }
+          t_last = tn;
+          if (tn >= t1) haveSeg = false;                                            // :1182
+          else t_i += dtSeg;
+          nAvail = s_ + 1;
+        }
+      }
+
+      // ---- evaluate: this lane's sample (:800-806, :910-927, :988-1011) ----
+      Color4 smp; smp.x = smp.y = smp.z = smp.w = 0.f;
+      int contributes = 0;
+      if (myExists) {
+        int listBegin, listSize;
+        float flcw;
+        if (a.leafBeginBits) {
+          const unsigned d = (unsigned)myRec;
+          listBegin = (int)(d & ((1u << a.leafBeginBits) - 1u));
+          listSize = (int)((d >> a.leafBeginBits) & ((1u << a.leafSizeBits) - 1u)) + 1;
+          flcw = __int_as_float((127 + (int)(d >> (a.leafBeginBits + a.leafSizeBits))) << 23);
+        } else {
+          const RegionInfo ri = a.sc.regionInfo[myRec];
+          listBegin = ri.listBegin; listSize = ri.listSize; flcw = ri.finestLevelCellWidth;
+        }
+        Basis B;
+        B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
+        const V3 pos = ray.org + myTs * ray.dir;
+#pragma unroll 1
+        for (int child = 0; child < listSize; child++) {
+          const unsigned at = 2u * (unsigned)(listBegin + child);
+          const int4 hb0 = a.sc.leafHdr[at], hb1 = a.sc.leafHdr[at + 1u];
+          addBasisFast<GRAD, 0, SMALL>(C, B, hb0, hb1, field0, pos);
+          myVisits++;
+        }
+        if (B.sumW > 1e-20f && myDt != 0.f) {
+          const float cellValue = fdivExact<FAST>(B.sumWV, B.sumW);
+          V3 grad = mk(0.f, 0.f, 0.f);
+          if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
+                              B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
+                              B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
+          smp = shadeSample<FAST>(C, ray, myDt, cellValue, grad, flcw, 0);
+          contributes = 1;
+        }
+      }
+
+      // ---- fold: the step's samples in order; every lane of the ray keeps the same pixel ----
+#pragma unroll 1
+      for (int s_ = 0; s_ < L; s_++) {
+        Color4 o;
+        o.x = __shfl(smp.x, lead + s_, 64); o.y = __shfl(smp.y, lead + s_, 64);
+        o.z = __shfl(smp.z, lead + s_, 64); o.w = __shfl(smp.w, lead + s_, 64);
+        const int oc = __shfl(contributes, lead + s_, 64);
+        if (!rayDone && s_ < nAvail) {
+          if (oc) compositeSample(pixelColor, o);
+          if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) rayDone = true;           // :1180
+        }
+      }
+      if (rayDone) {
+        pixelColor.x = pixelColor.x * pixelColor.w;                                // :1694-1696
+        pixelColor.y = pixelColor.y * pixelColor.w;
+        pixelColor.z = pixelColor.z * pixelColor.w;
+        pixelColor.w = 1.f;
+        break;
+      }
+      if (rayEnded) break;                                                         // lists exhausted, every sample folded
+    }
+
+    if (leader) {
+      float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (SURF) bgColor = a.surf[slot];
+      float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
+      float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
+      float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
+      if (fs.clockScale > 0.f) cr = clockHeat(fs.clockScale, clockBegin);          // :1703-1707
+      if (frameID > 0) {
+        const float4 acc = a.accum[slot];
+        cr += acc.x; cg += acc.y; cb += acc.z;
+      }
+      a.accum[slot] = make_float4(cr, cg, cb, 1.f);
+      const float div = frameID + 1.f;
+      cr = cr / div; cg = cg / div; cb = cb / div;
+      a.color[a.colorRowMajor ? size_t(px) + size_t(a.W) * py : slot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+    }
+  }
+  if (a.tileCost) {
+    // launch-order feedback in the one-lane kernel's unit: brick visits of the tile's longest ray
+    unsigned v = myVisits;
+    for (int off = 1; off < L; off <<= 1) v += (unsigned)__shfl_xor((int)v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down((int)v, off, 64));
+    if (lane == 0) atomicMax(&a.tileCost[tile], v);
+  }
+  if (C.guardTripped) atomicExch(a.errorFlag, 1);
+}
+
 hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s)
 {
   if (numTiles <= 0) return hipSuccess;
@@ -2529,11 +2797,15 @@ hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay
                                 else hipLaunchKernelGGL((renderFrameKdWideKernel<G, F, S, L, false>), grid, block, lds, s, a); } while (0)
   // 8 lanes per ray were measured and are not instantiated: on the critical-path probe (tests/gpu_wide_probe.py, C4,
   // rank 0 of 64) 1 / 2 / 4 / 8 lanes take 4.71 / 3.37 / 2.52 / 3.00 ms
-#define EXA_W3(G, F, S) do { if (lanesPerRay == 2) EXA_W4(G, F, S, 2); else EXA_W4(G, F, S, 4); } while (0)
+#define EXA_D4(G, F, S, L) do { if (small) hipLaunchKernelGGL((renderFrameKdDeepKernel<G, F, S, L, true>), grid, block, lds, s, a); \
+                                else hipLaunchKernelGGL((renderFrameKdDeepKernel<G, F, S, L, false>), grid, block, lds, s, a); } while (0)
+#define EXA_W3(G, F, S) do { if (lanesPerRay == 2) EXA_W4(G, F, S, 2); else if (lanesPerRay == 4) EXA_W4(G, F, S, 4); \
+                             else if (lanesPerRay == 8) EXA_D4(G, F, S, 8); else EXA_D4(G, F, S, 16); } while (0)
 #define EXA_W2(G, F) do { if (surf) EXA_W3(G, F, true); else EXA_W3(G, F, false); } while (0)
   if (grad) { if (fast) EXA_W2(true, true); else EXA_W2(true, false); }
   else      { if (fast) EXA_W2(false, true); else EXA_W2(false, false); }
 #undef EXA_W4
+#undef EXA_D4
 #undef EXA_W2
 #undef EXA_W3
   return hipGetLastError();

@@ -28,6 +28,12 @@ using namespace exa;
 #ifndef EXA_WIDE_WORK4
 #define EXA_WIDE_WORK4 1.88
 #endif
+#ifndef EXA_WIDE_TOP_LANES
+#define EXA_WIDE_TOP_LANES 4      // lanes per ray of the top class: 4 (wide march) or 8 / 16 (deep march)
+#endif
+#ifndef EXA_DEEP_WORK
+#define EXA_DEEP_WORK 2.2         // deep march: work of a tile relative to the one-lane march
+#endif
 
 namespace {
 
@@ -321,11 +327,15 @@ struct ExaHipRenderer {
   int statsMode = 1;                    // option stats_mode: what exa_hip_render_stats collects (1 work counters, 2 wave time by phase)
   int costPhase = 0;                    // 1: the next synchronous frame measures tile costs, then the tiles are re-ordered
   // wide march (L lanes per ray) for the tiles on the frame's critical path
-  int wideMode = 1;                     // option wide_march: 0 off, 1 by cost, 2 / 4 every tile with that many lanes (tests)
+  int wideMode = 1;                     // option wide_march: 0 off, 1 by cost, 2 / 4 / 8 / 16 every tile with that many lanes (tests)
+  int topLanes = EXA_WIDE_TOP_LANES;    // lanes per ray of the top class ("w4" below): 4 = wide march, 8 / 16 = deep march (option wide_top)
+  // listed leaves per ray of a wide / deep tile: kWideSegCap per window (wide march), 2048 in all (deep march)
+  static size_t segsPerRay(int lanes) { return lanes <= 4 ? size_t(lanes) * kWideSegCap : size_t(2048); }
   int numSimdWaves = 256 * 4 * 6;       // waves the device holds at the march kernel's occupancy
   DevBuf<int32_t> normalMap, wideMap;   // one-lane tiles in launch order; wide tiles, the 4-lane ones first
   DevBuf<float4> wideSegs;              // leaf lists of the wide march's window walkers (grown on demand)
   int nNormal = 0, nWide4 = 0, nWide2 = 0;
+  int lanesTopInUse = 4;                // lanes per ray of the nWide4 tiles of the current plan
   hipStream_t side4 = nullptr, side2 = nullptr, sideN = nullptr;
   hipEvent_t evFork = nullptr, evJoin4 = nullptr, evJoin2 = nullptr, evJoinN = nullptr;
   DevBuf<uint32_t> surfRnd;
@@ -516,8 +526,10 @@ struct ExaHipRenderer {
   {
     const size_t n = curMap.size();
     std::vector<int32_t> normal, w4, w2;
-    if (wideMode == 2 || wideMode == 4) {
-      (wideMode == 4 ? w4 : w2) = curMap;
+    int lanesTop = topLanes;
+    if (wideMode == 2 || wideMode == 4 || wideMode == 8 || wideMode == 16) {
+      (wideMode >= 4 ? w4 : w2) = curMap;
+      if (wideMode >= 4) lanesTop = wideMode;
     } else if (wideMode == 1 && costOfTile) {
       // Model constants: a critical tile finishes kSpeed2 (2 lanes) times sooner and costs kWork2 / kWork4
       // times the work; a loaded GPU steps a wave 1.3x slower.  Measured with the round-1 kernels (probe 6.0 -> 3.7 ->
@@ -527,7 +539,7 @@ struct ExaHipRenderer {
       // stays within 0.05 ms of the best one tried.
       // NOTE: the module owns exactly three side streams.  A fourth (tried for an 8-lane class) made two of the
       // streams that carry one frame's launches share a hardware queue, and the shard of 8 went from 4.6 to 7.0 ms.
-      const double kSpeed2 = EXA_WIDE_SPEED2, kWork2 = EXA_WIDE_WORK2, kWork4 = EXA_WIDE_WORK4, kLoaded = 1.3;
+      const double kSpeed2 = EXA_WIDE_SPEED2, kWork2 = EXA_WIDE_WORK2, kWork4 = lanesTop > 4 ? EXA_DEEP_WORK : EXA_WIDE_WORK4, kLoaded = 1.3;
       double fill = 0;
       for (size_t b = 0; b < n; b++) fill += 4.0 * (*costOfTile)[curMap[b]];
       fill *= kLoaded / numSimdWaves;
@@ -547,7 +559,7 @@ struct ExaHipRenderer {
     {
       // leaf lists: 16 B x kWideSegCap per window walker = 8 KiB per lane; keep them within 8 GiB by handing the
       // lightest wide tiles back to the one-lane march (forced modes on large frames)
-      const size_t perTile4 = size_t(kTilePixels) * 4 * kWideSegCap * sizeof(float4), perTile2 = perTile4 / 2;
+      const size_t perTile4 = size_t(kTilePixels) * segsPerRay(lanesTop) * sizeof(float4), perTile2 = size_t(kTilePixels) * segsPerRay(2) * sizeof(float4);
       const size_t budget = size_t(std::getenv("EXA_WIDE_BUDGET_GB") ? std::atoi(std::getenv("EXA_WIDE_BUDGET_GB")) : 8) << 30;
       while (w4.size() * perTile4 + w2.size() * perTile2 > budget) {
         if (!w2.empty()) { normal.push_back(w2.back()); w2.pop_back(); }
@@ -558,7 +570,7 @@ struct ExaHipRenderer {
     std::vector<int32_t> wide(w4);
     wide.insert(wide.end(), w2.begin(), w2.end());
     {
-      const size_t need = (w4.size() * 4 + w2.size() * 2) * size_t(kTilePixels) * kWideSegCap;
+      const size_t need = (w4.size() * segsPerRay(lanesTop) + w2.size() * segsPerRay(2)) * size_t(kTilePixels);
       if (need > wideSegs.n && wideSegs.alloc(need) != hipSuccess) {
         // no room for the leaf lists: the frame simply keeps the one-lane march
         (void)hipGetLastError();
@@ -570,8 +582,9 @@ struct ExaHipRenderer {
     HIP_TRY(this, normalMap.refill(normal.data(), normal.size()));
     HIP_TRY(this, wideMap.refill(wide.data(), wide.size()));
     nNormal = (int)normal.size(); nWide4 = (int)w4.size(); nWide2 = (int)w2.size();
+    lanesTopInUse = lanesTop;
     if (std::getenv("EXA_HIP_VERBOSE"))
-      std::fprintf(stderr, "[exa_hip] wide march: %d tiles x4 lanes, %d x2, %d one lane per ray\n", nWide4, nWide2, nNormal);
+      std::fprintf(stderr, "[exa_hip] wide march: %d tiles x%d lanes, %d x2, %d one lane per ray\n", nWide4, lanesTop, nWide2, nNormal);
     return 0;
   }
 
@@ -902,13 +915,13 @@ struct ExaHipRenderer {
           HIP_TRY(this, hipStreamWaitEvent(side4, evFork, 0));
           aw.wideTileMap = wideMap.p;
           aw.wideSegs = wideSegs.p;
-          HIP_TRY(this, launchRenderKdWide(aw, nWide4, 4, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side4));
+          HIP_TRY(this, launchRenderKdWide(aw, nWide4, lanesTopInUse, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side4));
           HIP_TRY(this, hipEventRecord(evJoin4, side4));
         }
         if (nWide2) {
           HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
           aw.wideTileMap = wideMap.p + nWide4;
-          aw.wideSegs = wideSegs.p + size_t(nWide4) * 4 * kTilePixels * kWideSegCap;
+          aw.wideSegs = wideSegs.p + size_t(nWide4) * segsPerRay(lanesTopInUse) * kTilePixels;
           HIP_TRY(this, launchRenderKdWide(aw, nWide2, 2, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side2));
           HIP_TRY(this, hipEventRecord(evJoin2, side2));
         }
@@ -1492,8 +1505,12 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "tile_feedback")) { h->feedback = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "wide_march")) {
-    if (value != 0 && value != 1 && value != 2 && value != 4) { h->fail("exa_hip_set_option: wide_march is 0, 1, 2 or 4"); return 1; }
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) { h->fail("exa_hip_set_option: wide_march is 0, 1, 2, 4, 8 or 16"); return 1; }
     h->wideMode = value; h->layoutDirty = true; return 0;
+  }
+  if (!std::strcmp(key, "wide_top")) {
+    if (value != 4 && value != 8 && value != 16) { h->fail("exa_hip_set_option: wide_top is 4, 8 or 16"); return 1; }
+    h->topLanes = value; h->layoutDirty = true; return 0;
   }
   if (!std::strcmp(key, "stats_mode")) {
     if (value != 1 && value != 2) { h->fail("exa_hip_set_option: stats_mode is 1 or 2"); return 1; }

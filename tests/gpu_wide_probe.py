@@ -10,7 +10,7 @@ case = Case(sc, W=2048, H=2048, grad=1, xf_domains=[(0.0, 1.0)])
 R = case.hip_renderer()
 R.setShard(0, 64)
 ref = None
-for lanes in (0, 2, 4):
+for lanes in (0, 2, 4, 8, 16):
     R.setOption("wide_march", lanes)
     R.setOption("tile_feedback", 0)
     img = R.render()
@@ -28,7 +28,7 @@ R.resizeFrameBuffer((1024, 1024))
 cam = __import__("owlexabrick_amd.harness", fromlist=["x"]).default_camera(*R.voxelSpaceBounds, 1024, 1024)
 R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
 base = None
-for lanes in (0, 2, 4):
+for lanes in (0, 2, 4, 8, 16):
     R.setOption("wide_march", lanes)
     R.render(); R.render()
     t = []

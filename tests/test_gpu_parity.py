@@ -326,10 +326,11 @@ def test_phase_time_variant_keeps_pixels_and_reports_cycles():
     assert all(c > 0 for c in pc[:4]) and st["samples"] == 0      # times, no work counters
 
 
-@pytest.mark.parametrize("lanes", [2, 4])
+@pytest.mark.parametrize("lanes", [2, 4, 8, 16])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_wide_march_is_bit_identical(name, lanes):
-    """wide_march = 2 / 4 marches every tile with that many lanes per ray (normally only the tiles on a
+    """wide_march = 2 / 4 (wide march) or 8 / 16 (deep march: the ray's next L samples across segment boundaries per
+    step) marches every tile with that many lanes per ray (normally only the tiles on a
     frame's critical path): consecutive samples evaluated side by side, composited in order — the same
     accumulation buffer bit for bit, over 2 accumulated frames (scenes with several primary channels keep
     the one-lane march)"""
