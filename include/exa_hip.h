@@ -268,7 +268,8 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes
  * per ray — the walk split into depth windows, consecutive samples evaluated side by side and composited in order,
  * bit-identical pixels; up to 8 GiB of device memory for the walkers' leaf lists — 0 = never,
- * 2 / 4 = every tile with that many lanes (tests); "prepass_split" 1 (default) = in a frame with surfaces the tiles whose iso marches are
+ * 2 / 4 / 8 / 16 = every tile with that many lanes (tests; 8 and 16 are the deep march, which takes a ray's next samples
+ * across segment boundaries); "wide_top" 4 (default) / 8 / 16 = lanes per ray of the most critical class of wide_march 1; "prepass_split" 1 (default) = in a frame with surfaces the tiles whose iso marches are
  * long (measured by the same frame that measures the tile costs) get their own pre-pass + march pipeline on a side stream,
  * beside the pre-pass + march of the other tiles (the pre-pass is bound by the latency of its longest rays, the march by
  * throughput), 0 = the whole pre-pass in front of the whole march; "ao_defer" 1 = the ambient-occlusion rays of the shaded hits are traced by a launch of their own,

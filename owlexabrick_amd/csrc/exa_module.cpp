@@ -539,7 +539,11 @@ struct ExaHipRenderer {
       // stays within 0.05 ms of the best one tried.
       // NOTE: the module owns exactly three side streams.  A fourth (tried for an 8-lane class) made two of the
       // streams that carry one frame's launches share a hardware queue, and the shard of 8 went from 4.6 to 7.0 ms.
-      const double kSpeed2 = EXA_WIDE_SPEED2, kWork2 = EXA_WIDE_WORK2, kWork4 = lanesTop > 4 ? EXA_DEEP_WORK : EXA_WIDE_WORK4, kLoaded = 1.3;
+      double kSpeed2 = EXA_WIDE_SPEED2;
+      const double kWork2 = EXA_WIDE_WORK2, kLoaded = 1.3;
+      double kWork4 = lanesTop > 4 ? EXA_DEEP_WORK : EXA_WIDE_WORK4;
+      if (const char *e = std::getenv("EXA_WIDE_WORK_TOP")) kWork4 = std::atof(e);          // calibration runs
+      if (const char *e = std::getenv("EXA_WIDE_SPEED2")) kSpeed2 = std::atof(e);
       double fill = 0;
       for (size_t b = 0; b < n; b++) fill += 4.0 * (*costOfTile)[curMap[b]];
       fill *= kLoaded / numSimdWaves;

@@ -8,7 +8,8 @@ import numpy as np
 sc = scenes.config("c4_exajet", scale=float(sys.argv[1]) if len(sys.argv) > 1 else 1.0)
 case = Case(sc, W=2048, H=2048, grad=1, xf_domains=[(0.0, 1.0)])
 R = case.hip_renderer()
-R.setShard(0, 64)
+shards = int(sys.argv[2]) if len(sys.argv) > 2 else 64      # 64: 256 tiles (one round of workgroups at 4 lanes per ray); 256: 64 tiles (one round at 16)
+R.setShard(0, shards)
 ref = None
 for lanes in (0, 2, 4, 8, 16):
     R.setOption("wide_march", lanes)
@@ -21,7 +22,7 @@ for lanes in (0, 2, 4, 8, 16):
     same = True if ref is None else bool(np.array_equal(img, ref))
     if ref is None:
         ref = img.copy()
-    print(f"critical-path probe (rank 0 of 64), lanes per ray {max(lanes, 1)}: {np.median(t):.3f} ms  (pixels identical: {same})", flush=True)
+    print(f"critical-path probe (rank 0 of {shards}), lanes per ray {max(lanes, 1)}: {np.median(t):.3f} ms  (pixels identical: {same})", flush=True)
 # work ratio: the whole 1024x1024 frame with every tile wide (throughput-bound), EXA_WIDE_BUDGET_GB must admit all tiles
 R.setShard(0, 1)
 R.resizeFrameBuffer((1024, 1024))
