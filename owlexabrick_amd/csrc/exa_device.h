@@ -43,6 +43,12 @@
                                 // C3 is bound by the latency of its longest rays there (3 / 4 / 5 waves: 21.08 / 21.07 / 21.62 ms per frame),
                                 // C5 by throughput (3 waves + the march header kept in registers across a one-brick segment: 13.9 instead of 10.9 ms)
 #endif
+#ifndef EXA_OPT_STACK8
+#define EXA_OPT_STACK8 0      // kd short stack with 8-byte entries (parent node + exit distance; far child and plane distance re-derived
+                              // at the pop): six entries where four 12-byte ones were.  Measured on C4 (round 3): restarts 18.8 M -> 5.8 M,
+                              // node steps -10 %, wave-level node steps -15 % — and the frame 22.66 -> 23.18 ms (inside camera 33.0 -> 33.2,
+                              // C3 + iso 17.9 -> 18.1): the node load and the division in front of every pop cost more than the restarts
+#endif
 #ifndef EXA_OPT_MED3
 #define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
 #endif
@@ -115,6 +121,9 @@ struct DeviceScene {
                             // Measured on C4 (stack/queue), bursts that end when no lane is dry: 4/4 22.42 ms, 3/5 22.56,
                             // 5/3 22.89, 2/6 23.41 (with bursts run until every queue is full: 4/4 24.62, 3/5 24.25)
 #endif
+// entries of the short stack in the LDS the 12-byte layout reserves (kKdStack / kKdStackMulti x 12 bytes per lane)
+enum { kKdStackEntries = EXA_OPT_STACK8 ? (EXA_KD_STACK * 12) / 8 : EXA_KD_STACK,
+       kKdStackMultiEntries = EXA_OPT_STACK8 ? (EXA_KD_STACK_MULTI * 12) / 8 : EXA_KD_STACK_MULTI };
 enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kKdStackMulti = EXA_KD_STACK_MULTI, kSegQueue = EXA_SEG_QUEUE,
        kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
        kWideSegCap = 256,

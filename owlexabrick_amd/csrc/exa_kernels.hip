@@ -1369,8 +1369,12 @@ struct KdWalk {
 };
 #define EXA_KD_DONE (EXA_KD_EMPTY + 1)
 
-template <int STATS, int KS = kKdStack>
-__device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, float *stackF)
+// EXA_OPT_STACK8: a stack entry is 8 bytes — the PARENT node and the exit distance of its interval — instead of 12 (far
+// child, entry and exit distance): the far child and its entry distance (the parent's plane distance, the same
+// expression (split - o) / d as when it was pushed, so the same bits) are re-derived from the parent node at the pop.
+// Six entries fit where four did, and the restarts of the short stack (a third of all node steps on C4) become rare.
+template <int STATS, int KS = kKdStackEntries, bool SMALL = false>
+__device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, float *stackF, const KdNodeDev *nodes, const Ray &ray)
 {
   const int count = w.pk.get(PK_SCOUNT);
   if (count > 0) {
@@ -1378,9 +1382,23 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, 
     head = head == 0 ? KS - 1 : head - 1;
     w.pk.set(PK_SHEAD, head);
     w.pk.set(PK_SCOUNT, count - 1);
+#if EXA_OPT_STACK8
+    const int parent = C.stack[head * kKdBlock];
+    w.tf = stackF[head * kKdBlock];
+    const int4 n = SMALL ? *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(nodes) + ((uint32_t)parent << 4))
+                         : *reinterpret_cast<const int4 *>(nodes + parent);
+    const int axis = n.y & 3;
+    const float ox = ray.org.x, oy = ray.org.y, oz = ray.org.z, dx = ray.dir.x, dy = ray.dir.y, dz = ray.dir.z;
+    float o = axis == 0 ? ox : oy, d = axis == 0 ? dx : dy;
+    o = axis == 2 ? oz : o;
+    d = axis == 2 ? dz : d;
+    w.tn = (__int_as_float(n.x) - o) / d;                   // the plane distance the push saw (d != 0: such a node never pushes)
+    w.ref = d > 0.f ? n.w : n.z;                            // the far child
+#else
     w.ref = C.stack[head * kKdBlock];
     w.tn = stackF[(2 * head) * kKdBlock];
     w.tf = stackF[(2 * head + 1) * kKdBlock];
+#endif
   } else if (w.pk.get(PK_DROPPED) && w.tf < w.tEnd) {
     C.count(ST_RESTARTS);
     w.ref = root;                      // short-stack restart: everything before tf is done
@@ -1402,7 +1420,7 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, 
 // ISOWALK: the iso march multiplies ray.tmax by dt_scale before every trace (exabrick.cu:1434), so the
 // walk is not clamped at the root; the current tmax clamps t1 at the leaf and ends the walk.
 // KS: entries of the lane's short stack (the multi-channel march runs with one fewer, see renderFrameKdKernel)
-template <bool ISOWALK, int STATS, bool SMALL = false, int KS = kKdStack>
+template <bool ISOWALK, int STATS, bool SMALL = false, int KS = kKdStackEntries>
 __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a,
                                        float *stackF, int *qRegion, float *qT, const Ray &ray, const int which,
                                        float &walkTmax, const float dtScale, const KdNodeDev *nodes, const int root)
@@ -1449,14 +1467,14 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     // until a trace reaches its far face or finds nothing (dt_scale <= 1: t0 >= t1 next time).
     if (!(ISOWALK && hit && t1 < w.tf)) w.ref = EXA_KD_EMPTY;
   }
-  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop<STATS, KS>(C, w, root, stackF);
+  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop<STATS, KS, SMALL>(C, w, root, stackF, nodes, ray);
   // With EXA_OPT_POP1 this is the only pop: a node that leaves nothing to descend into marks the subtree EMPTY and
   // the pop happens here at the start of the lane's next call, in front of that call's node stage — the same
   // sequence of subtrees, with one inlined copy of the pop instead of five for the wave's divergent lanes to run
 #if EXA_OPT_POP1
 #define EXA_KD_POP_LATER() (w.ref = EXA_KD_EMPTY)
 #else
-#define EXA_KD_POP_LATER() kdPop<STATS, KS>(C, w, root, stackF)
+#define EXA_KD_POP_LATER() kdPop<STATS, KS, SMALL>(C, w, root, stackF, nodes, ray)
 #endif
   // the popped subtree gets its own look at tmin / tmax in the next call
   if (w.ref < 0 || !(w.tf > walkTmin) || (ISOWALK && !(w.tn < walkTmax))) return;
@@ -1494,9 +1512,14 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
   } else if (nearAct) {
     if (farAct) {                                            // push far [ts,tf], go near [tn,ts]
       const int head = w.pk.get(PK_SHEAD), count = w.pk.get(PK_SCOUNT);
+#if EXA_OPT_STACK8
+      C.stack[head * kKdBlock] = w.ref;                      // the parent: far child and ts come back from it at the pop
+      stackF[head * kKdBlock] = w.tf;
+#else
       C.stack[head * kKdBlock] = farRef;
       stackF[(2 * head) * kKdBlock] = ts;
       stackF[(2 * head + 1) * kKdBlock] = w.tf;
+#endif
       w.pk.set(PK_SHEAD, head == KS - 1 ? 0 : head + 1);
       if (count == KS) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count + 1);
     }
@@ -1648,7 +1671,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
-  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStackEntries) * kKdBlock * 4) + threadIdx.x;
   int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
   float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
@@ -1790,7 +1813,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? 5 : EXA_PREPASS_WAVES)) void 
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
-  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStackEntries) * kKdBlock * 4) + threadIdx.x;
   int *qRegion = reinterpret_cast<int *>(sp0 + size_t(kKdStack) * kKdBlock * 12) + threadIdx.x;
   float *qT = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
@@ -1862,14 +1885,15 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
   // 25 KB instead of 28 KB of LDS and a sixth workgroup fits a CU (C3: 30.8 -> 29.4 ms; a shorter stack alone costs ~1 %:
   // a dropped entry is re-found by a restart from the root).  With three tables the sixth workgroup does not fit either
   // way and the 80-VGPR build only costs (3 channels on C4: +2 %): MULTI == 2 keeps 4 entries and 5 waves per SIMD.
-  constexpr int KS = MULTI == 1 ? kKdStackMulti : kKdStack;
+  constexpr int KSB = MULTI == 1 ? kKdStackMulti : kKdStack;                      // LDS: 12 bytes x KSB per lane for the stack
+  constexpr int KS = MULTI == 1 ? kKdStackMultiEntries : kKdStackEntries;         // entries the walk keeps there
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
   float *stackF = reinterpret_cast<float *>(sp0 + size_t(KS) * kKdBlock * 4) + threadIdx.x;
-  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(KS) * kKdBlock * 12) + threadIdx.x;
-  float *qT = reinterpret_cast<float *>(sp0 + size_t(KS) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
+  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(KSB) * kKdBlock * 12) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(sp0 + size_t(KSB) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
@@ -2190,11 +2214,11 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
     if (w.tn >= winLo && w.tn < w.tf) out[count++] = make_float4(__int_as_float(~w.ref), w.tn, w.tf, 0.f);   // caller: count < cap
     w.ref = EXA_KD_EMPTY;
   }
-  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > winLo))) kdPop(C, w, root, stackF);
+  if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > winLo))) kdPop(C, w, root, stackF, nodes, ray);
 #if EXA_OPT_POP1
 #define EXA_KD_POP_LATER() (w.ref = EXA_KD_EMPTY)
 #else
-#define EXA_KD_POP_LATER() kdPop(C, w, root, stackF)
+#define EXA_KD_POP_LATER() kdPop(C, w, root, stackF, nodes, ray)
 #endif
   if (w.ref < 0 || !(w.tf > winLo) || !(w.tn < winHi)) return;
   const int4 n = *reinterpret_cast<const int4 *>(nodes + w.ref);
@@ -2222,11 +2246,16 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
   } else if (nearAct) {
     if (farAct) {
       const int head = w.pk.get(PK_SHEAD), count_ = w.pk.get(PK_SCOUNT);
+#if EXA_OPT_STACK8
+      C.stack[head * kKdBlock] = w.ref;
+      stackF[head * kKdBlock] = w.tf;
+#else
       C.stack[head * kKdBlock] = farRef;
       stackF[(2 * head) * kKdBlock] = ts;
       stackF[(2 * head + 1) * kKdBlock] = w.tf;
-      w.pk.set(PK_SHEAD, head == kKdStack - 1 ? 0 : head + 1);
-      if (count_ == kKdStack) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count_ + 1);
+#endif
+      w.pk.set(PK_SHEAD, head == kKdStackEntries - 1 ? 0 : head + 1);
+      if (count_ == kKdStackEntries) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count_ + 1);
     }
     w.ref = nearRef;
     w.tf = ts;
@@ -2246,7 +2275,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
-  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStackEntries) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
@@ -2543,7 +2572,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdDeepKernel(const Ren
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
-  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStack) * kKdBlock * 4) + threadIdx.x;
+  float *stackF = reinterpret_cast<float *>(sp0 + size_t(kKdStackEntries) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
