@@ -1,7 +1,11 @@
-"""Channel-interleaved cell values for the multi-channel DVR march (option "interleave", default on): the module re-lays
-the primary channels as float[cell][channel] on the device and the march evaluates all channels of a sample per brick
-visit.  Same values, same sums in the same order: the frame must equal the field-by-field march bit for bit, and the
-oracle within the stated tolerance (the seeded families of tests/test_gpu_fuzz.py cover the latter with 2..4 fields)."""
+"""Where the cells lie in memory and how a frame is launched (round 3) — none of it may change a pixel:
+* `interleave` (default on): the module re-lays the primary channels as float[cell][channel] on the device and the
+  multi-channel DVR march evaluates all channels of a sample per brick visit.  Same values, same sums in the same order:
+  the frame must equal the field-by-field march bit for bit, and the oracle within the stated tolerance (the seeded
+  families of tests/test_gpu_fuzz.py cover the latter with 2..4 fields);
+* `brick_order`: the cells re-laid along a Morton curve of the brick centres;
+* `prepass_split`: tiles with long iso marches in their own pre-pass + march pipeline;
+* `ao_defer`: the AO rays of the shaded hits traced by their own launch over a compact hit list."""
 import numpy as np
 import pytest
 
