@@ -50,6 +50,42 @@ def test_config_expression_vector_and_errors():
         assert r.returncode == 1 and "error in opening config file" in r.stderr
 
 
+def test_exarender_flag_errors_are_reported_before_anything_runs():
+    """malformed --devices lists (the loop that never advanced), too many contour planes, unknown flags"""
+    for bad in (["--devices", "a"], ["--devices", "0;1"], ["--devices", "0,"], ["--devices", "-1"], ["--devices", ""]):
+        r = _run(["x.exa"] + bad)
+        assert r.returncode == 1 and "--devices wants a comma-separated list" in r.stderr, (bad, r.stderr)
+    r = _run(["x.exa", "--bogus"])
+    assert r.returncode == 1 and "unknown flag --bogus" in r.stderr
+    r = _run(["x.exa", "--contourplane", "1", "0", "0"])
+    assert r.returncode == 1 and "missing value" in r.stderr
+
+
+@pytest.mark.gpu
+def test_exarender_contour_plane_flags_match_the_binding():
+    """--contourplane nx ny nz offset / --contourchan c (exa/viewer.cpp:1199-1207, the viewer's panel set-up :673-690)"""
+    sc = scenes.amr(seed=3, root=(2, 2, 2), B=4, levels=3)
+    grey = np.repeat((np.arange(128, dtype=np.float32) / 127.0)[:, None], 4, axis=1)
+    W, H = 72, 56
+    with tempfile.TemporaryDirectory() as d:
+        cfg = scenes.write_exa(sc, d, "amr")
+        out = os.path.join(d, "o.ppm")
+        r = _run([cfg, "--size", str(W), str(H), "-o", out, "--frames", "1", "--xf-scale", "0.2",
+                  "--contourplane", "1", "0.3", "0.2", "0.45", "--contourplane", "0", "0", "1", "0.6"])
+        assert r.returncode == 0, r.stderr
+        cv = [np.float32(x) for x in r.stdout.split("camera")[1].split()[:12]]
+        cam = dict(pos=np.array(cv[0:3]), dir00=np.array(cv[3:6]), dirDu=np.array(cv[6:9]), dirDv=np.array(cv[9:12]))
+        data = open(out, "rb").read()
+        hdr = f"P6\n{W} {H}\n255\n".encode()
+        img = np.frombuffer(data[len(hdr):], dtype=np.uint8).reshape(H, W, 3)[::-1]
+    dom = (float(min(sc.fields[0].min(), 0.0)), float(max(sc.fields[0].max(), 0.0)))
+    case = Case(sc, W=W, H=H, grad=1, xf=grey, xf_domains=[dom], camera=cam, opacity_scale=0.2,
+                contour=[([1, 0.3, 0.2], 0.45, 0), ([0, 0, 1], 0.6, 0)])
+    h = case.run_hip()
+    assert np.array_equal(harness.unpack_rgba8(h[0])[..., :3], img)
+    assert (img.max(axis=-1) > 0).mean() > 0.05            # the planes are in the picture
+
+
 @pytest.mark.gpu
 def test_exarender_matches_binding_and_oracle():
     sc = scenes.amr(seed=3, root=(2, 2, 2), B=4, levels=3)
