@@ -289,7 +289,7 @@ def main():
     # start it now on one core so it overlaps the GPU part
     oracle_box = {}
     want_cpu = (args.cpu_baseline == "auto" and rank == 0 and world == 1 and args.iso is None and args.spp == 1
-                and len(scene.fields) == 1)
+                and len(scene.fields) == 1 and not os.environ.get("EXA_BENCH_SHARD"))     # (a rehearsed shard is not a frame)
 
     def build_oracle():
         from oracle import pyoracle as po          # bench.py's cpu_baseline leg may use the oracle
