@@ -170,8 +170,9 @@ RGBA_MAX_LSB = 1
 # A ray stops when its opacity reaches 0.98 (exabrick.cu:49,1180).  An ulp of difference in a
 # transcendental can move that decision by one sample for a rare pixel; the pixel then moves by
 # at most the remaining transmittance (0.02) times its colour.  Allowed for at most FLIP_FRACTION
-# of the pixels (2 pixels in a frame too small for that to be a whole pixel: 2 of 14 000 random frames had two);
-# every other pixel must meet ACCUM_ATOL/RTOL.
+# of the pixels (2 pixels in a frame too small for that to be a whole pixel: 2 of 14 000 random frames had two — one of
+# them, seed 803 of the odd-TF-domain family, is pinned in tests/test_gpu_fuzz.py; the floor only ever matters below
+# 6 000 pixels, above that FLIP_FRACTION allows three or more anyway); every other pixel must meet ACCUM_ATOL/RTOL.
 FLIP_BOUND = 0.021
 FLIP_FRACTION = 5e-4
 
