@@ -62,8 +62,8 @@ def _check_crop(acc_gpu, acc_cpu, win, frames, ao, what):
 class Config:
     """one scene, one oracle scene, one renderer — built once per configuration"""
 
-    def __init__(self, name, size, iso=None, ao=0, scale=1.0):
-        self.sc = scenes.config(name, scale=scale)
+    def __init__(self, name, size, iso=None, ao=0, scale=1.0, fields=None):
+        self.sc = scenes.config(name, scale=scale, fields=fields)
         nf = len(self.sc.fields)
         self.case = Case(self.sc, W=size, H=size, grad=1, iso=iso, ao=ao, xf_domains=[(0.0, 1.0)] * nf)
         self.R = self.case.hip_renderer()
@@ -230,5 +230,26 @@ def test_field_beyond_4_gib_takes_the_64_bit_offsets():
         base = _properties(cfg)
         win = (0, 0, size, size)
         _check_crop(base[1], cfg.oracle_frames(win), win, 1, 0, "C4 x1.25, whole frame")
+    finally:
+        cfg.close()
+
+
+def test_c4_three_channels_full_scale_interleaved_copy_beyond_4_gib():
+    """SURVEY 8(d)'s second data point for configs[3]: three DVR channels on the full exajet-like scene.  The
+    channel-interleaved copy of the three fields (7.7 GB) is larger than 4 GiB, so the interleaved march runs its general
+    64-bit address form on real > 4 GiB offsets while each field-major array still takes 32-bit offsets: the frame must
+    equal the field-by-field march bit for bit, and the whole frame the oracle within the stated tolerance"""
+    size = 384
+    cfg = Config("c4_exajet", size, fields=3)
+    try:
+        assert cfg.R.params.numPrimaryChannels == 3 and cfg.sc.num_cells * 3 * 4 > 2 ** 32
+        base = cfg.render_frames(2)
+        cfg.R.setOption("interleave", 0)
+        assert _same(cfg.render_frames(2), base), "field-by-field march"
+        cfg.R.setOption("interleave", 1)
+        cfg.R.setOption("brick_order", 1)
+        assert _same(cfg.render_frames(2), base), "cells re-laid along the Morton curve"
+        win = (0, 0, size, size)
+        _check_crop(base[1], cfg.oracle_frames(win, frames=2), win, 2, 0, "C4 with three channels, whole frame")
     finally:
         cfg.close()
