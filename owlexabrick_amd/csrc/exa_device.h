@@ -43,6 +43,18 @@
                                 // C3 is bound by the latency of its longest rays there (3 / 4 / 5 waves: 21.08 / 21.07 / 21.62 ms per frame),
                                 // C5 by throughput (3 waves + the march header kept in registers across a one-brick segment: 13.9 instead of 10.9 ms)
 #endif
+#ifndef EXA_OPT_SORG
+#define EXA_OPT_SORG 1        // march: the (wave-uniform) ray origin in scalar registers (three VGPRs less to keep alive; time within noise)
+#endif
+#ifndef EXA_OPT_BURSTPRIO
+#define EXA_OPT_BURSTPRIO 1   // march: walk bursts at raised wave priority (s_setprio 1; 0 = off).  A burst is a chain of dependent node
+                              // loads during which every lane of the wave waits.  C4 22.56 -> 22.38 ms (priority 1 / 2 / 3 alike), inside camera
+                              // 32.82 -> 32.50, three channels 41.2 -> 40.9, C3 + iso unchanged; the segment pops at raised priority as well
+                              // (EXA_OPT_POPPRIO) give the gain back
+#endif
+#ifndef EXA_OPT_POPPRIO
+#define EXA_OPT_POPPRIO 0     // march: segment pops at raised wave priority
+#endif
 #ifndef EXA_OPT_STACK8
 #define EXA_OPT_STACK8 0      // kd short stack with 8-byte entries (parent node + exit distance; far child and plane distance re-derived
                               // at the pop): six entries where four 12-byte ones were.  Measured on C4 (round 3): restarts 18.8 M -> 5.8 M,

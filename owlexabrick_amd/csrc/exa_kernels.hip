@@ -1953,6 +1953,12 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
     }
     surface_t_hit = ray.tmax;
     ray.org = xfmPoint(fs, ray.org);                                              // :1664-1668
+#if EXA_OPT_SORG
+    // the ray origin is the camera position in voxel space: the same value in every lane, so it lives in scalar registers
+    ray.org.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ray.org.x)));
+    ray.org.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ray.org.y)));
+    ray.org.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ray.org.z)));
+#endif
     ray.dir = xfmVector(fs, ray.dir);
     const float dt_scale = length(ray.dir);
     ray.dir = normalize(ray.dir);
@@ -2009,11 +2015,21 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       // (starting a burst only once 2 / 4 / 8 lanes are dry, the dry ones sitting iterations out: 23.4 / 23.8 / 25.0 ms)
       if (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
         C.lap(ST_T_WALK);
+#if EXA_OPT_BURSTPRIO
+        __builtin_amdgcn_s_setprio(EXA_OPT_BURSTPRIO);   // a burst is a chain of dependent node loads with every lane of the wave waiting
+#endif
         do {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
           if (want) kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
+#if EXA_OPT_BURSTPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
       }
+#if EXA_OPT_POPPRIO
+      const bool popping_ = anyLane(!haveSeg);
+      if (popping_) __builtin_amdgcn_s_setprio(EXA_OPT_POPPRIO);
+#endif
       if (!haveSeg) {
         // ---- next segment from this lane's queue ----
         C.lap(ST_T_SEG);
@@ -2055,6 +2071,9 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         C.count(ST_SAMPLE_EVALS);
       }
 
+#if EXA_OPT_POPPRIO
+      if (popping_) __builtin_amdgcn_s_setprio(0);
+#endif
       // ---- one brick visit ----
       C.lap(ST_T_BRICK);
       C.phase(ST_W_BRICK);
