@@ -129,6 +129,9 @@ typedef struct ExaHipStats {
   uint64_t walk_union_nodes;  /* option walk_probe: kd nodes visited, counted once per WAVE (the union over its 64 rays):
                                  what a wave-coherent (packet) walk would have to step through at least */
   uint64_t walk_probe_overflow; /* ... lanes that found their wave's probe table full (0 in a valid measurement) */
+  uint64_t wave_iters;        /* kd march: march iterations of every wave's longest ray, summed over the waves ...       */
+  uint64_t tile_iters;        /* ... and 4 x the slowest wave's per workgroup, summed: wave_iters / tile_iters = how evenly
+                                 the four waves of a workgroup finish (its LDS is held until the slowest one does)        */
 } ExaHipStats;
 
 typedef struct ExaHipRenderer ExaHipRenderer;

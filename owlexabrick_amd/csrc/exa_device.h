@@ -150,7 +150,7 @@ enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CO
                 // shader-clock cycles of the waves by phase (sum over waves): brick visit, sample epilogue, kd walk,
                 // segment pop, everything else (ray set-up, output)
                 ST_T_BRICK, ST_T_FINAL, ST_T_WALK, ST_T_SEG, ST_T_OTHER,
-                ST_RESTARTS, ST_UNION, ST_PROBE_OVERFLOW, ST_COUNT };
+                ST_RESTARTS, ST_UNION, ST_PROBE_OVERFLOW, ST_WAVE_ITERS, ST_TILE_ITERS, ST_COUNT };
 
 // a shaded surface hit whose ambient-occlusion rays aoRaysKdKernel traces: hit point + |cos| of the primary ray, normal +
 // ambient term, base colour + the LCG state its two samples draw from, pixel slot

@@ -2202,6 +2202,17 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
       if ((threadIdx.x & 63) == 0 && v) atomicAdd(&a.stats[i], v);
     }
+    // how evenly a workgroup's four waves finish (its LDS stays allocated until the slowest one does): sum of the
+    // waves' march iterations against 4 x the slowest wave's, over all workgroups
+    __shared__ unsigned wgMaxIters;
+    if (threadIdx.x == 0) wgMaxIters = 0;
+    __syncthreads();
+    unsigned v = marchIters;
+    for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down((int)v, off, 64));
+    if (lane == 0) atomicMax(&wgMaxIters, v);
+    __syncthreads();
+    if (lane == 0) atomicAdd(&a.stats[ST_WAVE_ITERS], (unsigned long long)v);
+    if (threadIdx.x == 0) atomicAdd(&a.stats[ST_TILE_ITERS], 4ull * wgMaxIters);
   }
 }
 

@@ -1605,6 +1605,7 @@ static int renderMulti(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, 
       for (int i = 0; i < 9; i++) sum.diag[i] += k[ST_W_BRICK + i];
       for (int i = 0; i < 5; i++) sum.phase_cycles[i] += k[ST_T_BRICK + i];
       sum.walk_restarts += k[ST_RESTARTS]; sum.walk_union_nodes += k[ST_UNION]; sum.walk_probe_overflow += k[ST_PROBE_OVERFLOW];
+      sum.wave_iters += k[ST_WAVE_ITERS]; sum.tile_iters += k[ST_TILE_ITERS];
     }
   }
   sum.pixels = uint64_t(h->W) * h->H;
@@ -1615,6 +1616,7 @@ static int renderMulti(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, 
     for (int i = 0; i < 9; i++) sum.diag[i] = keep.diag[i];
     for (int i = 0; i < 5; i++) sum.phase_cycles[i] = keep.phase_cycles[i];
     sum.walk_restarts = keep.walk_restarts; sum.walk_union_nodes = keep.walk_union_nodes; sum.walk_probe_overflow = keep.walk_probe_overflow;
+    sum.wave_iters = keep.wave_iters; sum.tile_iters = keep.tile_iters;
   }
   h->last = sum;
   if (!dstIsDevice && rgba8) {
@@ -1657,6 +1659,7 @@ static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, h
     for (int i = 0; i < 9; i++) h->last.diag[i] = c[ST_W_BRICK + i];
     for (int i = 0; i < 5; i++) h->last.phase_cycles[i] = c[ST_T_BRICK + i];
     h->last.walk_restarts = c[ST_RESTARTS]; h->last.walk_union_nodes = c[ST_UNION]; h->last.walk_probe_overflow = c[ST_PROBE_OVERFLOW];
+    h->last.wave_iters = c[ST_WAVE_ITERS]; h->last.tile_iters = c[ST_TILE_ITERS];
     h->walkProbe.release();
   }
   h->last.pixels = px;

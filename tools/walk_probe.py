@@ -49,5 +49,7 @@ out = {"config": args.config, "scale": args.scale, "size": W, "camera": args.cam
        "union_over_shipped_executions": st["walk_union_nodes"] / max(1, d[4]),
        "lane_steps_per_union_node": st["nodes_visited"] / max(1, st["walk_union_nodes"]),
        "short_stack_restarts": st["walk_restarts"], "restarts_per_segment": st["walk_restarts"] / max(1, st["segments"]),
-       "nodes_per_segment": st["nodes_visited"] / max(1, st["segments"])}
+       "nodes_per_segment": st["nodes_visited"] / max(1, st["segments"]),
+       "wave_march_iterations_summed": st["wave_iters"], "four_times_slowest_wave_per_workgroup_summed": st["tile_iters"],
+       "workgroup_evenness": st["wave_iters"] / max(1, st["tile_iters"])}
 print(json.dumps(out, indent=1))
