@@ -197,6 +197,10 @@ def main():
     ap.add_argument("--camera", default="default", choices=["default", "closeup"],
                     help="default: the viewer's 3/4 view from outside (viewer.cpp:1289-1294); closeup: inside the refined zone")
     ap.add_argument("--fields", type=int, default=None, help="number of scalar fields = DVR channels (default: the configuration's)")
+    ap.add_argument("--bricks-file", default=None,
+                    help="[n,7] int32 .npy of brick headers (size.xyz, lower.xyz, level): the configuration's scene on these bricks "
+                         "instead of the generator's own 8^3 blocks, e.g. profiles/c4_exajet_exabuilder_bricks7.npy = the bricks this "
+                         "repo's exaBuilder makes of the scene's cells (tools/builder_bench.py --save-bricks7)")
     ap.add_argument("--no-grad", action="store_true", help="gradient shading off (reference default is on)")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-seconds", type=float, default=45.0)
@@ -280,7 +284,8 @@ def main():
 
     # ---------------- scene: generate, prepare, upload ----------------
     t0 = time.time()
-    scene = scenes.config(args.config, scale=args.scale, threads=host_threads, fields=args.fields)
+    ext_bricks = np.load(args.bricks_file) if args.bricks_file else None
+    scene = scenes.config(args.config, scale=args.scale, threads=host_threads, fields=args.fields, bricks7=ext_bricks)
     t_gen = time.time() - t0
     log(f"scene {args.config} scale {args.scale}: {scene.num_cells:.4g} cells, {scene.bricks7.shape[0]} bricks, "
         f"levels {scene.meta['levels_hist']} ({t_gen:.1f}s)")
@@ -545,7 +550,8 @@ def main():
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "frames_in_flight": F,
             "msamples_per_s": samples_total / 1e6 * fps * args.spp,
-            "config": {"workload": f"{args.config} (seed {cfg['seed']:#x} procedural AMR, scale {args.scale}): "
+            "config": {"workload": f"{args.config} (seed {cfg['seed']:#x} procedural AMR, scale {args.scale}"
+                                   f"{', bricks from ' + os.path.basename(args.bricks_file) if args.bricks_file else ''}): "
                                    f"{scene.num_cells} cells / {scene.bricks7.shape[0]} bricks / "
                                    f"{int(prep.scene.numRegions)} regions, {W}x{H} DVR"
                                    f"{' of %d channels' % len(scene.fields) if len(scene.fields) > 1 else ''}, "
@@ -594,7 +600,8 @@ def main():
         key = f"{args.config}@{args.scale}@{W}"
         traffic = vi = None
         stock = (world == 1 and not rehearse and args.iso is None and args.spp == 1 and not args.ao
-                 and args.camera == "default" and args.fields is None and not args.no_grad and not args.option)   # what profiles/hbm_traffic.json was measured on
+                 and args.camera == "default" and args.fields is None and not args.no_grad and not args.option
+                 and not args.bricks_file)   # what profiles/hbm_traffic.json was measured on
         profiled = any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
         if args.pmc == "on" or (args.pmc == "auto" and args.cpu_baseline == "auto" and not profiled):
             out["_pmc_child"] = True          # measured below, after the process group is gone
@@ -676,6 +683,7 @@ def main():
                      "--in-flight", str(F), "--spp", str(args.spp), "--camera", args.camera]
             child += ["--no-grad"] if args.no_grad else []
             child += ["--fields", str(args.fields)] if args.fields is not None else []
+            child += ["--bricks-file", os.path.abspath(args.bricks_file)] if args.bricks_file else []
             child += ["--iso", str(args.iso)] if args.iso is not None else []
             child += ["--ao"] if args.ao else []
             for kv in args.option:

@@ -265,13 +265,22 @@ class _GenHandle:
 
 
 def generated(kind="exajet", seed=1, root=(8, 4, 4), B=8, levels=4, band=1.0, fields=1, threads=0,
-              fill=True, name=None):
-    """seeded AMR scene from the C++ generator; arrays are views on the generator's memory."""
+              fill=True, name=None, bricks7=None):
+    """seeded AMR scene from the C++ generator; arrays are views on the generator's memory.
+    bricks7 ([n,7] int32 size.xyz, lower.xyz, level): the same scene — domain, feature, field functions — on a brick list
+    given from outside instead of the generator's own B^3 blocks (e.g. the bricks exaBuilder made of the scene's cells)."""
     import ctypes as C
     L = _scenegen_lib()
     h = C.c_void_p()
     rootN = (C.c_int32 * 3)(*root)
-    rc = L.exa_scenegen_create(seed, rootN, B, levels, KINDS[kind], band, fields, threads, int(fill), C.byref(h))
+    if bricks7 is not None:
+        b7 = np.ascontiguousarray(bricks7, dtype=np.int32).reshape(-1, 7)
+        L.exa_scenegen_create_from_bricks.argtypes = [C.c_uint64, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                                      C.c_int32, C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]
+        rc = L.exa_scenegen_create_from_bricks(seed, rootN, B, levels, KINDS[kind], band, fields, threads, b7.ctypes.data,
+                                               b7.shape[0], C.byref(h))
+    else:
+        rc = L.exa_scenegen_create(seed, rootN, B, levels, KINDS[kind], band, fields, threads, int(fill), C.byref(h))
     if rc:
         raise RuntimeError(f"scene generator failed (rc={rc}; more than 2^31 cells?)")
     keep = _GenHandle(L, h)
@@ -296,15 +305,16 @@ def generated(kind="exajet", seed=1, root=(8, 4, 4), B=8, levels=4, band=1.0, fi
     return sc
 
 
-def config(name, scale=1.0, threads=0, fill=True, fields=None):
+def config(name, scale=1.0, threads=0, fill=True, fields=None, bricks7=None):
     """one of CONFIGS; scale < 1 shrinks the root grid (tests), keeping the feature; `fields` overrides the number
-    of scalar fields (C4 with 3 channels as a second data point)."""
+    of scalar fields (C4 with 3 channels as a second data point); `bricks7`: the configuration's scene on an
+    external brick list (see generated)."""
     c = dict(CONFIGS[name])
     if fields is not None:
         c["fields"] = int(fields)
     root = tuple(max(1, int(round(r * scale))) for r in c.pop("root"))
     kind = c.pop("kind")
-    return generated(kind=kind, root=root, threads=threads, fill=fill, name=name, **c)
+    return generated(kind=kind, root=root, threads=threads, fill=fill, name=name, bricks7=bricks7, **c)
 
 
 def write_exa(scene, directory, name="scene", remap=None, meshes=None):

@@ -118,3 +118,39 @@ def test_builder_on_seeded_random_cell_sets(seed):
     from fuzz_builder import check
     bad, desc = check(seed)
     assert not bad, (desc, bad)
+
+
+def test_generated_scene_on_builder_made_bricks_holds_the_same_cells():
+    """bench.py --bricks-file: the procedural scene re-instantiated on the bricks exaBuilder makes of its cells
+    (scenes.config(..., bricks7=...)) — every cell of the original scene appears once, with the value the field functions
+    give at its position"""
+    sc = scenes.config("c4_exajet", scale=0.06, threads=4)
+    cells = cells_of(sc)
+    r, data = run_builder(cells)
+    assert r.returncode == 0, r.stderr
+    raw = np.frombuffer(data, dtype=np.int32)
+    hdrs, at = [], 0
+    while at < raw.size:
+        h = raw[at:at + 7]
+        hdrs.append(h.copy())
+        at += 7 + int(h[0]) * int(h[1]) * int(h[2])
+    b7 = np.stack(hdrs)
+    assert len(b7) < len(sc.bricks7)                                    # the builder merges the 8^3 blocks
+    sb = scenes.config("c4_exajet", scale=0.06, threads=4, bricks7=b7)
+    assert sb.num_cells == sc.num_cells and np.array_equal(sb.bricks7, b7)
+
+    def keyed(scene):
+        key, val, at = [], [], 0
+        for sx, sy, sz, x, y, z, l in np.asarray(scene.bricks7, dtype=np.int64):
+            n = sx * sy * sz
+            k = np.stack(np.meshgrid(np.arange(sz), np.arange(sy), np.arange(sx), indexing="ij"), -1).reshape(-1, 3)[:, ::-1]   # x fastest
+            p = np.array([x, y, z]) + k * (1 << l)
+            key.append((p[:, 0] << 42) | (p[:, 1] << 21) | p[:, 2] | (np.int64(l) << 60))
+            val.append(np.asarray(scene.fields[0])[np.asarray(scene.cellIDs[at:at + n])])
+            at += n
+        key, val = np.concatenate(key), np.concatenate(val)
+        order = np.argsort(key)
+        return key[order], val[order]
+    ka, va = keyed(sc)
+    kb, vb = keyed(sb)
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)

@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--frames", type=int, default=12)
     ap.add_argument("--out", default="/tmp/exa_builder_bench")
     ap.add_argument("--builder-args", default="", help="extra exaBuilder flags, e.g. '--max-leaf-width 32'")
+    ap.add_argument("--save-bricks7", default=None, help="write the builder's brick headers ([n,7] int32: size.xyz, lower.xyz, level) as .npy "
+                                                         "(input of bench.py --bricks-file)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     sc = scenes.config("c4_exajet", scale=args.scale)
@@ -106,6 +108,18 @@ def main():
     scal.tofile(os.path.join(args.out, "built_0.scalars"))
     _, t_build = run([os.path.join(HOST, "exaBuilder"), os.path.join(args.out, "built.cells"), "-o",
                       os.path.join(args.out, "built.bricks")] + args.builder_args.split())
+    if args.save_bricks7:
+        hdrs = []
+        with open(os.path.join(args.out, "built.bricks"), "rb") as f:        # size[3], lower[3], level, cellIDs[] per brick
+            while True:
+                h = f.read(28)
+                if len(h) < 28:
+                    break
+                h = np.frombuffer(h, dtype=np.int32)
+                hdrs.append(h.copy())
+                f.seek(4 * int(h[0]) * int(h[1]) * int(h[2]), 1)
+        np.save(args.save_bricks7, np.stack(hdrs).astype(np.int32))
+        print(f"[builder_bench] {len(hdrs)} brick headers -> {args.save_bricks7}", file=sys.stderr, flush=True)
     with open(os.path.join(args.out, "built.exa"), "w") as f:
         f.write("bricks built.bricks\nscalar field0 built_0.scalars\n")
     r = render(os.path.join(args.out, "built.exa"), args.size, args.frames)

@@ -173,10 +173,23 @@ struct Gen {
     numCells = nb * per;
   }
 
+  // bricks given from outside (e.g. the bricks exaBuilder made of this scene's cells): same domain, same field functions
+  void adopt(const int32_t *b7, size_t nb)
+  {
+    const int top = P.levels - 1;
+    F.kind = P.kind;
+    for (int k = 0; k < 3; k++) F.ext[k] = float(P.rootN[k] * (P.B << top));
+    F.unit = std::min(F.ext[0], std::min(F.ext[1], F.ext[2]));
+    bricks7.assign(b7, b7 + 7 * nb);
+    numCells = 0;
+    for (size_t b = 0; b < nb; b++) numCells += uint64_t(b7[7 * b]) * uint64_t(b7[7 * b + 1]) * uint64_t(b7[7 * b + 2]);
+  }
+
   void fill()
   {
     const size_t nb = bricks7.size() / 7;
-    const size_t per = size_t(P.B) * P.B * P.B;
+    std::vector<size_t> begin(nb + 1, 0);
+    for (size_t b = 0; b < nb; b++) begin[b + 1] = begin[b] + size_t(bricks7[7 * b]) * size_t(bricks7[7 * b + 1]) * size_t(bricks7[7 * b + 2]);
     fields.clear();
     for (int f = 0; f < P.numFields; f++) fields.emplace_back(new float[numCells]);
     cellIDs.reset(new int32_t[numCells]);
@@ -190,10 +203,10 @@ struct Gen {
         for (size_t b = b0; b < b1; b++) {
           const int32_t *r = &bricks7[7 * b];
           const float cw = float(1 << r[6]);
-          size_t i = b * per;
-          for (int iz = 0; iz < P.B; iz++)
-            for (int iy = 0; iy < P.B; iy++)
-              for (int ix = 0; ix < P.B; ix++, i++) {
+          size_t i = begin[b];
+          for (int iz = 0; iz < r[2]; iz++)
+            for (int iy = 0; iy < r[1]; iy++)
+              for (int ix = 0; ix < r[0]; ix++, i++) {
                 const float x = r[3] + (ix + 0.5f) * cw, y = r[4] + (iy + 0.5f) * cw, z = r[5] + (iz + 0.5f) * cw;
                 float wake;
                 const float d = F.body(x, y, z, wake);
@@ -246,6 +259,26 @@ int exa_scenegen_create(uint64_t seed, const int32_t rootN[3], int32_t B, int32_
   G->g.run();
   if (G->g.numCells > 0x7fffffffull) { if (fill) { delete G; return 2; } }   // 32-bit brick offsets (Brick.h:70)
   if (fill) G->g.fill();
+  *out = G;
+  return 0;
+}
+// the same scene (domain, feature, field functions of `kind` / `seed` / `rootN` / `B` / `levels`) on a brick list given from
+// outside, bricks7 = numBricks x {size.xyz, lower.xyz, level}: e.g. the bricks exaBuilder made of the scene's cells
+int exa_scenegen_create_from_bricks(uint64_t seed, const int32_t rootN[3], int32_t B, int32_t levels, int32_t kind,
+                                    float band, int32_t numFields, int32_t threads, const int32_t *bricks7, uint64_t numBricks,
+                                    ExaSceneGen **out)
+{
+  if (!out || !bricks7 || numBricks == 0 || B < 1 || levels < 1 || levels > 8 || numFields < 1 || numFields > 10) return 1;
+  for (uint64_t b = 0; b < numBricks; b++) {
+    const int32_t *r = bricks7 + 7 * b;
+    if (r[0] < 1 || r[1] < 1 || r[2] < 1 || r[6] < 0 || r[6] > 30) return 1;
+  }
+  ExaSceneGen *G = new ExaSceneGen;
+  G->g.P = Params{ seed, { rootN[0], rootN[1], rootN[2] }, B, levels, kind, band, numFields,
+                   threads > 0 ? threads : (int)std::max(1u, std::thread::hardware_concurrency()) };
+  G->g.adopt(bricks7, (size_t)numBricks);
+  if (G->g.numCells > 0x7fffffffull) { delete G; return 2; }
+  G->g.fill();
   *out = G;
   return 0;
 }
