@@ -55,6 +55,9 @@
 #ifndef EXA_OPT_POPPRIO
 #define EXA_OPT_POPPRIO 0     // march: segment pops at raised wave priority
 #endif
+#ifndef EXA_OPT_RSQ
+#define EXA_OPT_RSQ 1         // fast_math: gradient-shading factor with one transcendental (rsq) instead of three (sqrt, sqrt, rcp)
+#endif
 #ifndef EXA_OPT_STACK8
 #define EXA_OPT_STACK8 0      // kd short stack with 8-byte entries (parent node + exit distance; far child and plane distance re-derived
                               // at the pop): six entries where four 12-byte ones were.  Measured on C4 (round 3): restarts 18.8 M -> 5.8 M,

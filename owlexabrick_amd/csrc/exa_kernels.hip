@@ -404,6 +404,8 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
     uint32_t rowLL, rowHL, rowLH, rowHH;                      // cell index of the pair's first cell, per (y,z) row
     if (EXA_OPT_MUL24 && SMALL) {
       // SMALL: every factor below 2^24 and every product below 2^32 (checked per scene on the host)
+      // (the compiler turns this one __umul24 into the quarter-rate v_mul_lo_u32; forcing v_mul_u32_u24 with inline asm
+      // measured 22.25 against 22.19 ms — the asm pins the schedule — so it stays)
       const uint32_t sxy = __umul24((uint32_t)sx, (uint32_t)sy);
       const uint32_t zl = __umul24((uint32_t)czl, sxy) + (begin + (uint32_t)bx);
       const uint32_t zh = __umul24((uint32_t)czh, sxy) + (begin + (uint32_t)bx);
@@ -641,6 +643,20 @@ __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, flo
   Color4 sample = lookupXF<FAST, HAVE_RCP>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic, rcpRange);
   // the reference compares with `int finestLevelCellWidth` * 1e-6f (exabrick.cu:1124,1001); the width is an
   // integer-valued float (a power of two >= 1, checked at scene creation), so the int round trip is the identity
+#if EXA_OPT_RSQ
+  if (FAST) {
+    // fast_math: transcendental instructions issue at a quarter of the rate, and this block had three of them (sqrt for the
+    // threshold, sqrt and rcp for the factor).  The threshold test on the squares and one reciprocal square root keep the
+    // shading factor within 2 ulp of the library form (it only scales a colour) at one transcendental
+    const float g2 = dot(gradient, gradient);
+    const float thr = finestLevelCellWidth * 1e-6f;
+    if (g2 > thr * thr) {
+      const V3 lightDir = -ray.dir;
+      const float scale = fabsf(dot(lightDir, gradient)) * __builtin_amdgcn_rsqf(g2 * dot(lightDir, lightDir));
+      sample.x *= scale; sample.y *= scale; sample.z *= scale;
+    }
+  } else
+#endif
   if (fsqrt<FAST>(dot(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
     const float scale = fdiv<FAST>(fabsf(dot(lightDir, gradient)), fsqrt<FAST>(dot(gradient, gradient) * dot(lightDir, lightDir)));
