@@ -2021,6 +2021,12 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
     if (FAST && !MULTI)
       xfRcpRange0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
                         __builtin_amdgcn_rcpf((fs.xfDomain[0][1] - fs.xfDomain[0][0]) + 1e-20f))));
+    // ... and with the interleaved march one per channel (a transcendental per channel and sample otherwise)
+    float xfRcpRangeN[NCH ? NCH : 1];
+#pragma unroll
+    for (int c = 0; c < (NCH ? NCH : 1); c++)
+      xfRcpRangeN[c] = (FAST && NCH) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
+                           __builtin_amdgcn_rcpf((fs.xfDomain[c][1] - fs.xfDomain[c][0]) + 1e-20f)))) : 0.f;
 
     unsigned iter = 0;
     for (;; iter++) {
@@ -2124,7 +2130,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
             const float cellValue = fdivExact<FAST>(wv, B.sumW);
             V3 grad = mk(0.f, 0.f, 0.f);
             if (GRAD) grad = mk(B.sumW * sd.x - wv * B.sumDC.x, B.sumW * sd.y - wv * B.sumDC.y, B.sumW * sd.z - wv * B.sumDC.z);
-            integrateVolume<FAST, STATS, false>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, c, 0.f);
+            integrateVolume<FAST, STATS, FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, c, xfRcpRangeN[c]);
           }
         }
 #pragma unroll
