@@ -2117,6 +2117,9 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       if (child < listSize) continue;
 
       // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
+#if EXA_OPT_EPIPRIO
+      __builtin_amdgcn_s_setprio(EXA_OPT_EPIPRIO);
+#endif
       C.lap(ST_T_FINAL);
       C.phase(ST_W_FINAL);
       if (NCH) {
@@ -2146,6 +2149,9 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0;
+#if EXA_OPT_EPIPRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
       if (MULTI && !NCH) {
         chan++;
         if (chan < numChannels) {
