@@ -504,8 +504,13 @@ struct ExaHipRenderer {
       HIP_TRY(this, hipMemcpy(pre.data(), tileCostPre.p, pre.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
       uint32_t maxP = 0;
       for (size_t b = 0; b < n; b++) maxP = std::max(maxP, pre[curMap[b]]);
-      // heavy: a longest iso march above an eighth of the frame's longest (and long enough to matter at all)
-      const uint32_t thr = std::max<uint32_t>(64u, maxP / 8u);
+      // heavy: a longest iso march above 1/32 of the frame's longest (and long enough to matter at all)
+      // (C3 / C5 with the threshold at max/8 | >= 64 steps: 16.81 / 1444 ms, max/32 | 16: 16.61 / 1444, every tile with any iso
+      // step: 16.59 / 1444 — on C5 only 9 % of the tiles have any; profiles/r03_prepass_split_threshold.txt)
+      uint32_t div = 32, minSteps = 16;
+      if (const char *e = std::getenv("EXA_PREPASS_SPLIT_DIV")) div = (uint32_t)std::max(1, std::atoi(e));          // calibration runs
+      if (const char *e = std::getenv("EXA_PREPASS_SPLIT_MIN")) minSteps = (uint32_t)std::max(0, std::atoi(e));
+      const uint32_t thr = std::max<uint32_t>(minSteps, maxP / div);
       std::vector<int32_t> cheap, heavy;
       for (size_t b = 0; b < n; b++) (pre[curMap[b]] > thr ? heavy : cheap).push_back(curMap[b]);
       if (!heavy.empty() && !cheap.empty()) {
