@@ -107,35 +107,49 @@ def spawn_ranks(n):
 _B = "(true|false)"
 FRAME_KERNELS = {"march": rf"renderFrameKdKernel<{_B}, {_B}, \d, {_B}, 0, {_B}(, \d)?>|renderFrameKernel<{_B}, {_B}, 0>",   # <GRAD, FAST, MULTI, SURF, STATS, SMALL, NCH> / <GRAD, ISO, STATS>
                  "march_wide": r"renderFrameKdWideKernel<",
-                 "surfaces_prepass": r"surfacePrepassKdKernel<0, (true|false)>"}
+                 "surfaces_prepass": rf"surfacePrepassKdKernel<0, {_B}, {_B}>",                                          # <STATS, ISO_ONLY, AO_DEFER>
+                 "ao_rays": r"aoRaysKdKernel<"}
+PMC_MARKER = "profileMarkerKernel"           # bench.py brackets its timed frames with two of these (option profile_marker)
 PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE", "SQ_INSTS_VALU"))     # HBM reads alone (MI355X_MICROARCH.md: separate passes)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0       # G wave64-VALU instructions / s: 1024 SIMDs, one every 2 cycles, 2.4 GHz
 F32_VECTOR_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 vector peak (FMA counted as 2)
 
 
-def pmc_frame_totals(csv_files, classes=FRAME_KERNELS):
+def pmc_frame_totals(csv_files, classes=FRAME_KERNELS, frames=None):
     """rocprofv3 counter_collection CSVs -> ({kernel class: {counter: mean per FRAME}}, frames).  A dispatch's value is the
-    sum of its rows (one row per counter instance: XCD, channel, ...); a frame is one dispatch of the "march" class, the
-    other classes' dispatches (wide tiles, surfaces pre-pass) belong to the frames they were launched with."""
+    sum of its rows (one row per counter instance: XCD, channel, ...).  With two marker dispatches in the list (PMC_MARKER)
+    only the dispatches between them count — the timed frames, without warm-up, cost-measurement and counting frames —
+    and `frames` is how many frames the run put there.  Without markers every dispatch counts and a frame is one dispatch
+    of the "march" class (true for frames that launch the march once: no split pre-pass plan)."""
     import csv
     import re
-    tot, disp = {}, {}
+    rows = []
     for f in csv_files:
         with open(f, newline="") as fh:
-            for row in csv.DictReader(fh):
-                for cls, rx in classes.items():
-                    if re.search(rx, row["Kernel_Name"]):
-                        d = tot.setdefault(cls, {})
-                        d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
-                        disp.setdefault((cls, row["Counter_Name"]), set()).add((f, row["Dispatch_Id"]))
-                        break
-    frames = max((len(v) for (cls, _), v in disp.items() if cls == "march"), default=0)
-    if not frames:
+            rows += [(f, int(r["Dispatch_Id"]), r["Kernel_Name"], r["Counter_Name"], float(r["Counter_Value"])) for r in csv.DictReader(fh)]
+    marks = {}
+    for f, did, name, _, _ in rows:
+        if PMC_MARKER in name:
+            marks.setdefault(f, set()).add(did)
+    bracket = {f: (min(m), max(m)) for f, m in marks.items() if len(m) >= 2}
+    tot, disp = {}, {}
+    for f, did, name, counter, value in rows:
+        if bracket and not (f in bracket and bracket[f][0] < did < bracket[f][1]):
+            continue
+        for cls, rx in classes.items():
+            if re.search(rx, name):
+                d = tot.setdefault(cls, {})
+                d[counter] = d.get(counter, 0.0) + value
+                disp.setdefault((cls, counter), set()).add((f, did))
+                break
+    if not (bracket and frames):
+        frames = max((len(v) for (cls, _), v in disp.items() if cls == "march"), default=0)
+    if not frames or "march" not in tot:
         return {}, 0
     return {cls: {c: v / frames for c, v in d.items()} for cls, d in tot.items()}, frames
 
 
-def live_pmc(child_args, seconds=300.0, extra_env=None):
+def live_pmc(child_args, seconds=300.0, extra_env=None, frames=None):
     """HBM bytes and VALU wave-instructions per frame, by kernel class, measured in THIS run: for each counter group a child
     `rocprofv3 --pmc ... -- python3 bench.py <same workload> --steps 2` (counters only, no trace domains; the parent is
     idle meanwhile).  Returns ({class: {counter: mean per frame}}, frames) or (None, reason)."""
@@ -148,7 +162,7 @@ def live_pmc(child_args, seconds=300.0, extra_env=None):
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
     out_dir = tempfile.mkdtemp(prefix="exa_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", EXA_BENCH_CPU_THREADS="2", EXA_BENCH_NO_LATENCY="1")
+    env = dict(os.environ, TMPDIR="/tmp", EXA_BENCH_CPU_THREADS="2", EXA_BENCH_NO_LATENCY="1", EXA_BENCH_MARKERS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
               "EXA_BENCH_FORCE_DIST", "EXA_BENCH_SHARD", "EXA_BENCH_SPAWNED", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
@@ -169,7 +183,8 @@ def live_pmc(child_args, seconds=300.0, extra_env=None):
             if p.returncode != 0:
                 tail = (err or b"").decode(errors="replace").strip().splitlines()[-1:] or [""]
                 return None, f"pass {i} ({' '.join(counters)}) exited with {p.returncode}: {tail[0][:200]}"
-            tot, frames = pmc_frame_totals(glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True))
+            tot, frames = pmc_frame_totals(glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True),
+                                           frames=frames)
             for c in counters:
                 if c not in tot.get("march", {}):
                     return None, f"pass {i}: no dispatch of the march kernel carries {c}"
@@ -212,6 +227,9 @@ def main():
     ap.add_argument("--tile-order", type=int, default=int(os.environ.get("EXA_TILE_ORDER", "4")))
     ap.add_argument("--accel", type=int, default=int(os.environ.get("EXA_ACCEL", "1")),
                     help="1 = region kd-tree walked front to back (default), 0 = LBVH restarted per segment")
+    ap.add_argument("--basis-form", type=int, default=int(os.environ.get("EXA_BENCH_BASIS_FORM", "-1")), choices=[-1, 0, 1],
+                    help="association of the eight-corner basis sums, on the GPU and in the CPU baseline alike: 0 = the reference's "
+                         "source order, 1 = per axis with fused multiply-adds (DESIGN.md 2); -1 = the module's default")
     ap.add_argument("--iso", type=float, default=None, help="enable one implicit iso-surface at this value (channel 0)")
     ap.add_argument("--ao", action="store_true", help="ambient-occlusion rays on surface hits (2 per hit, reference default)")
     ap.add_argument("--spp", type=int, default=1, help="frames accumulated per step (frameID 0..spp-1); a step is one converged frame")
@@ -318,6 +336,7 @@ def main():
     shard_rank, shard_world = (int(x) for x in rehearse.split(",")) if rehearse else (rank, world)
 
     F = args.in_flight if args.in_flight > 0 else (3 if shard_world > 1 else 1)
+    basis_form = args.basis_form if args.basis_form >= 0 else binding.DEFAULT_BASIS_FORM
 
     def make_renderer():
         R = binding.Renderer(prep, device=local_rank)
@@ -328,6 +347,7 @@ def main():
             # the wide march shortens a lone frame's critical path at the price of extra work; with frames in flight
             # the next frame fills the GPU instead and the extra work only costs (rank 0 of 8: 2.9 vs 4.6 ms per frame)
             R.setOption("wide_march", 0)
+        R.setOption("basis_form", basis_form)
         for kv in args.option:
             k, v = kv.split("=")
             R.setOption(k, int(v))
@@ -461,12 +481,18 @@ def main():
     if use_dist:
         dist.barrier()
     kernel_ms = []
+    markers = bool(os.environ.get("EXA_BENCH_MARKERS"))        # a PMC child: bracket the timed frames in the dispatch list
+    if markers:
+        R.setOption("profile_marker", 1)
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
         if F == 1:
             kernel_ms.append(R.stats()["kernel_ms"])       # the step's last launch (HIP events on the launch stream)
     torch.cuda.synchronize()
+    if markers:
+        R.setOption("profile_marker", 2)
+        torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
@@ -557,6 +583,10 @@ def main():
                                    f"{' of %d channels' % len(scene.fields) if len(scene.fields) > 1 else ''}, "
                                    f"{'camera inside the refined zone, ' if args.camera == 'closeup' else ''}dt 0.5, alpha ramp, "
                                    f"gradient shading {'off' if args.no_grad else 'on'}, space skipping on, frameID 0",
+                       "basis_form": f"{basis_form}: " + ("eight-corner basis sums in the reference's source order"
+                                                          if basis_form == 0 else
+                                                          "eight-corner basis sums associated per axis with fused multiply-adds; the CPU "
+                                                          "baseline / crop check evaluates the same sequence (or_set_basis_form)"),
                        "frames_in_flight": (f"{F}: frame k on renderer handle k % {F} (own scene copy, accumulation buffer and stream), "
                                             f"frame k+{F} waits for frame k; every frame is rendered completely and gathered; "
                                             f"kernel_ms is a lone frame's launch") if F > 1 else "1 (every frame synchronous)",
@@ -622,6 +652,7 @@ def main():
             oracle_thread.join()
             S = oracle_box["scene"]
             S.set_xf(0, xf)
+            S.set_basis_form(basis_form)            # the checker evaluates the same association as the kernels
             fs = po.FrameState()
             harness.fill_frame_state(fs, cam, [scene.value_range], xfOpacityScale=1.0, frameID=0)
             P = po.Params(0.5, 1, 0, 0 if args.no_grad else 1, 1, 1, 1)
@@ -682,6 +713,7 @@ def main():
                      "--tile-order", str(args.tile_order), "--accel", str(args.accel), "--cpu-baseline", "off", "--pmc", "off",
                      "--in-flight", str(F), "--spp", str(args.spp), "--camera", args.camera]
             child += ["--no-grad"] if args.no_grad else []
+            child += ["--basis-form", str(args.basis_form)]
             child += ["--fields", str(args.fields)] if args.fields is not None else []
             child += ["--bricks-file", os.path.abspath(args.bricks_file)] if args.bricks_file else []
             child += ["--iso", str(args.iso)] if args.iso is not None else []
@@ -690,7 +722,9 @@ def main():
                 child += ["--option", kv]
             extra = {"EXA_BENCH_SHARD": f"{shard_rank},{shard_world}"} if shard_world > 1 else {}
             t = time.perf_counter()
-            vals, n = live_pmc(child, extra_env=extra)
+            # the measured line so far goes to stderr first: if a PMC child is interrupted from outside, the frame rate is not lost
+            log("result before the live PMC passes (roofline.achieved / frac / traffic pending): " + json.dumps(out))
+            vals, n = live_pmc(child, extra_env=extra, frames=2 * args.spp)      # the child times 2 steps of spp frames each
             shard_note = " (the shard of this rank)" if shard_world > 1 else ""
             if vals:
                 fetch = sum(d.get("FETCH_SIZE", 0.0) for d in vals.values())

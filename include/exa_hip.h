@@ -271,15 +271,23 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * (default) = tiles whose longest ray would outlast the rest of the frame (multi-GPU shards) march with 2 or 4 lanes
  * per ray — the walk split into depth windows, consecutive samples evaluated side by side and composited in order,
  * bit-identical pixels; up to 8 GiB of device memory for the walkers' leaf lists — 0 = never,
- * 2 / 4 / 8 / 16 = every tile with that many lanes (tests; 8 and 16 are the deep march, which takes a ray's next samples
- * across segment boundaries); "wide_top" 4 (default) / 8 / 16 = lanes per ray of the most critical class of wide_march 1; "prepass_split" 1 (default) = in a frame with surfaces the tiles whose iso marches are
+ * 2 / 4 = every tile with that many lanes (tests); "prepass_split" 1 (default) = in a frame with surfaces the tiles whose iso marches are
  * long (measured by the same frame that measures the tile costs) get their own pre-pass + march pipeline on a side stream,
  * beside the pre-pass + march of the other tiles (the pre-pass is bound by the latency of its longest rays, the march by
  * throughput), 0 = the whole pre-pass in front of the whole march; "ao_defer" 1 = the ambient-occlusion rays of the shaded hits are traced by a launch of their own,
  * one ray per lane over a compact list of the hits, 0 (default) = inline behind each pixel's primary ray; "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
  * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change; "walk_probe" 1 = the
  * counting variant also records every wave's SET of visited kd nodes (128 KiB of device memory per wave) and reports its
- * size summed over the waves as walk_union_nodes (a diagnostic of how coherent the 64 walks of a wave are).
+ * size summed over the waves as walk_union_nodes (a diagnostic of how coherent the 64 walks of a wave are);
+ * "profile_marker" N = launch an empty kernel (profileMarkerKernel) on the null stream now: a bracket in a profiler's
+ * dispatch list, no effect on any frame.
+ * "basis_form" selects the association of the eight-corner sums of addBasisFunctions (programs/exabrick.cu:620-777):
+ * 1 (default) = per axis — x-pairs, then y, then z, weight sums as products of per-axis sums — with fused multiply-adds
+ * (49 instead of 116 floating-point operations per brick with derivatives), 0 = the reference's source order with every
+ * product and sum rounded separately.  The reference binary computes neither literally (nvcc contracts a*b+c by
+ * default and CMakeLists.txt passes no -fmad=false); the CPU oracle restates both operation for operation
+ * (or_set_basis_form) and the kernels equal it in either.  Form 1 against form 0: |d accum| <= 1e-3, RGBA8 <= 1 LSB
+ * (tests/test_basis_form.py).  Environment EXA_BASIS_FORM sets the initial value.
  * Two knobs move results within the stated float tolerance: "fast_math" 1 (default)
  * evaluates the opacity correction powf as exp2(dt*log2(x)) on the hardware
  * transcendental units (~2 ulp), 0 uses the library powf (<1 ulp); "tf_filter" 1 (default) holds the

@@ -106,6 +106,8 @@ struct OrScene {
   KdNode   *nodes; size_t numNodes, capNodes;
   float     xf[OR_MAX_CHANNELS][OR_NUM_XF_VALUES][4];
   float     tfFracMagic;   /* 32768: filter fraction held in 1.8 fixed point (CUDA tex1D); 0: full precision */
+  int       basisForm;     /* 0: addBasisFunctions in the reference's source order (the definition, default);
+                              1: the same eight-corner sums associated per axis, x -> y -> z, with fused multiply-adds */
   float    *meshVerts; int32_t *meshTris; size_t numVerts, numTris;   /* all surfaces, concatenated */
   /* streamline tracer state (OptixRenderer.h:160-170) */
   int tracerEnabled, tracerChannels[3], numTraces, numTimesteps;
@@ -412,6 +414,7 @@ void or_set_xf(OrScene *S, int chan, const float *rgba128)
 /* 1 (default): the tex1D filter weight in 9-bit fixed point with 8 fractional bits, as the CUDA C
  * programming guide publishes it; 0: full-precision weight */
 void or_set_tf_filter(OrScene *S, int cudaFixedPoint) { S->tfFracMagic = cudaFixedPoint ? 32768.f : 0.f; }
+void or_set_basis_form(OrScene *S, int form) { S->basisForm = form ? 1 : 0; }
 
 /* ------------------------------------------------------------------ */
 /* pixel helpers                                                       */
@@ -710,6 +713,90 @@ static void add_basis_functions(Ctx *C, Basis *B, int need_derivative, int brick
 #undef CORNER
 }
 
+/* Second association of the same sums (or_set_basis_form(S, 1)).
+ *
+ * The reference's source adds the eight corners one after the other, each weight built as (wz*wy)*wx (:644-774).  The
+ * reference BINARY does not compute that sequence either: nvcc contracts a*b+c into fused multiply-adds by default and
+ * CMakeLists.txt passes no -fmad=false, so which roundings the shipped renderer performs is a property of nvcc's
+ * instruction selection.  Both sequences are therefore restatements of the same real-valued expression
+ *     sumWV += SUM_zyx wz*wy*wx*s_zyx        sumW  += SUM_zyx wz*wy*wx
+ *     sumD  += SUM_zyx grad(wz*wy*wx)*s_zyx  sumDC += SUM_zyx grad(wz*wy*wx)
+ * over the corners that lie inside the brick.  "Inside" is a product of per-axis predicates, so the per-axis weights of
+ * an outside corner are set to 0 (and its value is not read: it counts as +0) and the triple sum factors:
+ *     row (z,y):  a = wxl*s_l + wxh*s_h                d = mxl*s_l + mxh*s_h         (mx = d wx / dx = -1 | +1 | 0)
+ *     y:          A_z = wyl*a_zl + wyh*a_zh            DX_z = wyl*d_zl + wyh*d_zh    DY_z = myl*a_zl + myh*a_zh
+ *     z:          sumWV += wzl*A_l + wzh*A_h           sumD.x += wzl*DX_l + wzh*DX_h sumD.y += ... DY   sumD.z += mzl*A_l + mzh*A_h
+ *     weights:    sumW += (Sz*Sy)*Sx    sumDC.x += (Sz*Sy)*Mx    sumDC.y += (Sz*Sx)*My    sumDC.z += (Sy*Sx)*Mz
+ * with S = wl + wh and M = ml + mh per axis.  Every `p*q + r` below is ONE fused multiply-add (fmaf), every other
+ * operation one IEEE binary32 operation, in exactly this order; the HIP kernels execute the same sequence
+ * (exa_kernels.hip: addBasisFactored).  49 operations per brick with derivatives where the source order takes 116. */
+static void add_basis_functions_factored(Ctx *C, Basis *B, int need_derivative, int brickID, v3 pos, int channel)
+{
+  const OrBrick *brick = &C->S->bricks[brickID];
+  const float cellWidth = (float)(1 << brick->level);
+  C->st.brick_visits++;
+
+  /* position in the brick, low cell index and fraction: as in the source order (:624-632) */
+  const v3 lower = V3((float)brick->lower[0], (float)brick->lower[1], (float)brick->lower[2]);
+  const v3 localPos = vsub(vdiv(vsub(pos, lower), v3s(cellWidth)), v3s(0.5f));
+  int lx = f2i(floorf(localPos.x)), ly = f2i(floorf(localPos.y)), lz = f2i(floorf(localPos.z));
+  lx = lx > -1 ? lx : -1; ly = ly > -1 ? ly : -1; lz = lz > -1 ? lz : -1;
+  const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
+  const v3 frac = vsub(localPos, V3((float)lx, (float)ly, (float)lz));
+  const v3 neg_frac = vsub(v3s(1.f), frac);
+  const int sx = brick->size[0], sy = brick->size[1], sz = brick->size[2];
+  /* the reference's in-brick tests, per axis (:642-643, :659, ...) */
+  const int vlx = lx >= 0 && lx < sx, vhx = hx < sx;
+  const int vly = ly >= 0 && ly < sy, vhy = hy < sy;
+  const int vlz = lz >= 0 && lz < sz, vhz = hz < sz;
+  const float wxl = vlx ? neg_frac.x : 0.f, wxh = vhx ? frac.x : 0.f;
+  const float wyl = vly ? neg_frac.y : 0.f, wyh = vhy ? frac.y : 0.f;
+  const float wzl = vlz ? neg_frac.z : 0.f, wzh = vhz ? frac.z : 0.f;
+  const float mxl = vlx ? -1.f : 0.f, mxh = vhx ? 1.f : 0.f;
+  const float myl = vly ? -1.f : 0.f, myh = vhy ? 1.f : 0.f;
+  const float mzl = vlz ? -1.f : 0.f, mzh = vhz ? 1.f : 0.f;
+  /* cell values; a corner outside the brick is not read */
+  float s[2][2][2];
+  for (int iz = 0; iz < 2; iz++)
+    for (int iy = 0; iy < 2; iy++)
+      for (int ix = 0; ix < 2; ix++) {
+        const int ok = (ix ? vhx : vlx) && (iy ? vhy : vly) && (iz ? vhz : vlz);
+        s[iz][iy][ix] = ok ? get_scalar(C, brick, ix ? hx : lx, iy ? hy : ly, iz ? hz : lz, channel) : 0.f;
+      }
+  float A[2], DX[2], DY[2];
+  for (int iz = 0; iz < 2; iz++) {
+    float a[2], d[2];
+    for (int iy = 0; iy < 2; iy++) {
+      a[iy] = fmaf(wxh, s[iz][iy][1], wxl * s[iz][iy][0]);
+      if (need_derivative) d[iy] = fmaf(mxh, s[iz][iy][1], mxl * s[iz][iy][0]);
+    }
+    A[iz] = fmaf(wyh, a[1], wyl * a[0]);
+    if (need_derivative) {
+      DX[iz] = fmaf(wyh, d[1], wyl * d[0]);
+      DY[iz] = fmaf(myh, a[1], myl * a[0]);
+    }
+  }
+  B->sumWV = fmaf(wzh, A[1], fmaf(wzl, A[0], B->sumWV));
+  const float Sx = wxl + wxh, Sy = wyl + wyh, Sz = wzl + wzh;
+  const float zy = Sz * Sy;
+  B->sumW = fmaf(zy, Sx, B->sumW);
+  if (need_derivative) {
+    B->sumD.x = fmaf(wzh, DX[1], fmaf(wzl, DX[0], B->sumD.x));
+    B->sumD.y = fmaf(wzh, DY[1], fmaf(wzl, DY[0], B->sumD.y));
+    B->sumD.z = fmaf(mzh, A[1], fmaf(mzl, A[0], B->sumD.z));
+    const float Mx = mxl + mxh, My = myl + myh, Mz = mzl + mzh;
+    B->sumDC.x = fmaf(zy, Mx, B->sumDC.x);
+    B->sumDC.y = fmaf(Sz * Sx, My, B->sumDC.y);
+    B->sumDC.z = fmaf(Sy * Sx, Mz, B->sumDC.z);
+  }
+}
+
+static inline void add_basis(Ctx *C, Basis *B, int need_derivative, int brickID, v3 pos, int channel)
+{
+  if (C->S->basisForm) add_basis_functions_factored(C, B, need_derivative, brickID, pos, channel);
+  else                 add_basis_functions(C, B, need_derivative, brickID, pos, channel);
+}
+
 /* exabrick.cu:781-806 samplePoint */
 static int sample_point(Ctx *C, float *value, int leafID, v3 pos, int channel)
 {
@@ -717,7 +804,7 @@ static int sample_point(Ctx *C, float *value, int leafID, v3 pos, int channel)
   const int32_t *childList = &C->S->leafList[region->leafListBegin];
   Basis B; memset(&B, 0, sizeof(B));
   for (int childID = 0; childID < region->leafListSize; childID++)
-    add_basis_functions(C, &B, 0, childList[childID], pos, channel);
+    add_basis(C, &B, 0, childList[childID], pos, channel);
   if (B.sumW <= 1e-20f) return 0;
   *value = B.sumWV / B.sumW;
   return 1;
@@ -730,7 +817,7 @@ static int sample_point_with_derivative(Ctx *C, float *value, v3 *derivatives, i
   const int32_t *childList = &C->S->leafList[region->leafListBegin];
   Basis B; memset(&B, 0, sizeof(B));
   for (int childID = 0; childID < region->leafListSize; childID++)
-    add_basis_functions(C, &B, 1, childList[childID], pos, channel);
+    add_basis(C, &B, 1, childList[childID], pos, channel);
   if (B.sumW <= 1e-20f) return 0;
   *value = B.sumWV / B.sumW;
   *derivatives = V3(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,

@@ -92,6 +92,7 @@ def lib():
         L.or_voxel_bounds.argtypes = [vp, fp, fp]
         L.or_set_xf.argtypes = [vp, C.c_int, vp]
         L.or_set_tf_filter.argtypes = [vp, C.c_int]
+        L.or_set_basis_form.argtypes = [vp, C.c_int]
         L.or_set_triangles.argtypes = [vp, vp, sz, vp, sz]
         L.or_reset_tracer.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_float, vp]
         L.or_advance_tracer.restype = C.c_int
@@ -193,6 +194,10 @@ class OracleScene:
     def set_tf_filter(self, cuda_fixed_point):
         """1 (default) = CUDA tex1D filter weight in 1.8 fixed point, 0 = full precision"""
         lib().or_set_tf_filter(self.h, int(cuda_fixed_point))
+
+    def set_basis_form(self, form):
+        """0 (default) = addBasisFunctions in the reference's source order, 1 = the per-axis association with fmaf"""
+        lib().or_set_basis_form(self.h, int(form))
 
     def reset_tracer(self, enabled, channels, num_traces, num_timesteps, steplen, seeds):
         sd = np.ascontiguousarray(seeds, dtype=np.float32).reshape(num_traces, 3)

@@ -15,6 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EXA_HIP_LIB") or os.path.join(_HERE, "libexa_hip.so")
 
 NUM_XF_VALUES, MAX_CHANNELS, MAX_ISO, MAX_CONTOUR = 128, 10, 2, 3
+# the module's default of option "basis_form" (exa_module.cpp): association of the eight-corner basis sums
+DEFAULT_BASIS_FORM = 1
 
 
 class _Iso(C.Structure):

@@ -50,23 +50,17 @@
 #define EXA_OPT_BURSTPRIO 1   // march: walk bursts at raised wave priority (s_setprio 1; 0 = off).  A burst is a chain of dependent node
                               // loads during which every lane of the wave waits.  C4 22.56 -> 22.38 ms (priority 1 / 2 / 3 alike), inside camera
                               // 32.82 -> 32.50, three channels 41.2 -> 40.9, C3 + iso unchanged; the segment pops at raised priority as well
-                              // (EXA_OPT_POPPRIO) give the gain back
+                              // gave the gain back (removed)
 #endif
 #ifndef EXA_OPT_EPIPRIO
 #define EXA_OPT_EPIPRIO 1     // march: sample epilogue at raised wave priority as well (its LDS reads and transcendentals are a dependent chain):
                               // C4 22.13 -> 21.94 ms on top of the burst priority; levels 1 / 2 / 3 of either alike
 #endif
-#ifndef EXA_OPT_POPPRIO
-#define EXA_OPT_POPPRIO 0     // march: segment pops at raised wave priority
-#endif
 #ifndef EXA_OPT_RSQ
 #define EXA_OPT_RSQ 1         // fast_math: gradient-shading factor with one transcendental (rsq) instead of three (sqrt, sqrt, rcp)
 #endif
-#ifndef EXA_OPT_STACK8
-#define EXA_OPT_STACK8 0      // kd short stack with 8-byte entries (parent node + exit distance; far child and plane distance re-derived
-                              // at the pop): six entries where four 12-byte ones were.  Measured on C4 (round 3): restarts 18.8 M -> 5.8 M,
-                              // node steps -10 %, wave-level node steps -15 % — and the frame 22.66 -> 23.18 ms (inside camera 33.0 -> 33.2,
-                              // C3 + iso 17.9 -> 18.1): the node load and the division in front of every pop cost more than the restarts
+#ifndef EXA_BASIS_FORM
+#define EXA_BASIS_FORM 0      // which association of the basis sums this translation unit of exa_kernels.hip is compiled for
 #endif
 #ifndef EXA_OPT_MED3
 #define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
@@ -141,8 +135,7 @@ struct DeviceScene {
                             // 5/3 22.89, 2/6 23.41 (with bursts run until every queue is full: 4/4 24.62, 3/5 24.25)
 #endif
 // entries of the short stack in the LDS the 12-byte layout reserves (kKdStack / kKdStackMulti x 12 bytes per lane)
-enum { kKdStackEntries = EXA_OPT_STACK8 ? (EXA_KD_STACK * 12) / 8 : EXA_KD_STACK,
-       kKdStackMultiEntries = EXA_OPT_STACK8 ? (EXA_KD_STACK_MULTI * 12) / 8 : EXA_KD_STACK_MULTI };
+enum { kKdStackEntries = EXA_KD_STACK, kKdStackMultiEntries = EXA_KD_STACK_MULTI };
 enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kKdStackMulti = EXA_KD_STACK_MULTI, kSegQueue = EXA_SEG_QUEUE,
        kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
        kWideSegCap = 256,
@@ -226,20 +219,32 @@ hipError_t buildLbvhTopologyDevice(const float *boxes, uint32_t numPrims, BvhNod
                                    std::vector<uint32_t> &internalNodesPerDepth, hipStream_t s);
 
 // ---- launchers implemented in exa_kernels.hip ----
-hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s);
+// The kernels that evaluate the hat basis are compiled twice, once per association of the eight-corner sums of
+// addBasisFunctions (exabrick.cu:620-777): namespace form0 = the reference's source order (-DEXA_BASIS_FORM=0, the
+// definition), form1 = per axis with fused multiply-adds (-DEXA_BASIS_FORM=1; option "basis_form", oracle:
+// or_set_basis_form).  One translation unit each (exa_kernels_f0.o / exa_kernels_f1.o).
+#define EXA_FORM_LAUNCHERS                                                                                              \
+  hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s);          \
+  hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s);                     \
+  hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf,                        \
+                            int stats /*0, 1 counters, 2 phase times*/, hipStream_t s);                                 \
+  hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf,    \
+                                hipStream_t s);                                                                         \
+  /* computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel */                        \
+  hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s);
+namespace form0 { EXA_FORM_LAUNCHERS }
+namespace form1 { EXA_FORM_LAUNCHERS }
+#undef EXA_FORM_LAUNCHERS
+
+// ---- kernels that never sample (compiled once, with form 0) ----
 hipError_t launchVolumeActivity(const DeviceScene &sc, const ExaHipFrameState &fs, const ExaHipParams &p,
                                 const float4 *xf, uint8_t *active, float tfFracMagic, hipStream_t s);
 hipError_t launchIsoActivity(const DeviceScene &sc, const ExaHipFrameState &fs, uint8_t *active, hipStream_t s);
 // refit one height class of internal nodes: box of each child = union below it
 hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const float *domain,
                        const uint8_t *active, hipStream_t s);
-hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s);
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats /*0, 1 counters, 2 phase times*/, hipStream_t s);
-hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
 hipError_t launchKdRefit(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
-// computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel
-hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s);
 // brick b's cells from srcBegin[b] to dstBegin[b] in every field (src -> dst), then `begin` of every brick record / march header
 hipError_t launchPermuteBricks(const float *src, float *dst, const uint32_t *srcBegin, const uint32_t *dstBegin, int4 *bricks,
                                unsigned long long numBricks, int4 *leafHdr, const int32_t *leafList, unsigned long long leafListSize,
@@ -248,5 +253,6 @@ hipError_t launchPermuteBricks(const float *src, float *dst, const uint32_t *src
 hipError_t launchInterleave(const DeviceScene &sc, unsigned long long totalCells, int nch, float *out, hipStream_t s);
 hipError_t launchUntile(const uint32_t *gathered, unsigned long long shardStride, int world,
                         int W, int H, uint32_t *out, hipStream_t s);
+hipError_t launchProfileMarker(int tag, hipStream_t s);
 
 } // namespace exa

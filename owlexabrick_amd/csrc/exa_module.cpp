@@ -28,12 +28,9 @@ using namespace exa;
 #ifndef EXA_WIDE_WORK4
 #define EXA_WIDE_WORK4 1.88
 #endif
-#ifndef EXA_WIDE_TOP_LANES
-#define EXA_WIDE_TOP_LANES 4      // lanes per ray of the top class: 4 (wide march) or 8 / 16 (deep march)
-#endif
-#ifndef EXA_DEEP_WORK
-#define EXA_DEEP_WORK 2.2         // deep march: work of a tile relative to the one-lane march
-#endif
+
+// the launchers of the sampling kernels exist once per association of the basis sums (exa_device.h)
+#define EXA_FORM(fn) (basisForm ? form1::fn : form0::fn)
 
 namespace {
 
@@ -222,7 +219,9 @@ struct ExaHipRenderer {
   // device by the first frame that marches 2..4 channels; the field-major arrays of the ABI stay for everything else)
   DevBuf<float> cellsIl;
   int ilChannels = 0;
+  int ilNoMemory = 0;                // channel count whose interleaved copy could not be allocated (not tried again)
   int interleave = 1;                // option "interleave"
+  int basisForm = 1;                 // option "basis_form": 1 (default) = the eight-corner basis sums per axis with fused multiply-adds, 0 = in the reference's source order
   int addr64 = 0;                    // option "addr64": the general 64-bit address form even where 32-bit offsets would do (tests)
   uint64_t totalCells = 0;
   // Order of the bricks' cells in memory (option brick_order): 0 = as uploaded (the running `begin` of
@@ -230,6 +229,7 @@ struct ExaHipRenderer {
   // brick's `begin`, so the module may move them; switching re-lays the fields on the device.
   std::vector<uint32_t> beginUploaded, beginMorton;   // per brick
   int brickOrder = 0, brickOrderWanted = 0;
+  bool brickOrderPossible = true;   // the scene has the reference's layout (fields at f * totalCells, begins a partition): cells may be moved
   uint64_t numBricks = 0, leafListSize = 0;
   int applyBrickOrder(hipStream_t s)
   {
@@ -327,10 +327,9 @@ struct ExaHipRenderer {
   int statsMode = 1;                    // option stats_mode: what exa_hip_render_stats collects (1 work counters, 2 wave time by phase)
   int costPhase = 0;                    // 1: the next synchronous frame measures tile costs, then the tiles are re-ordered
   // wide march (L lanes per ray) for the tiles on the frame's critical path
-  int wideMode = 1;                     // option wide_march: 0 off, 1 by cost, 2 / 4 / 8 / 16 every tile with that many lanes (tests)
-  int topLanes = EXA_WIDE_TOP_LANES;    // lanes per ray of the top class ("w4" below): 4 = wide march, 8 / 16 = deep march (option wide_top)
-  // listed leaves per ray of a wide / deep tile: kWideSegCap per window (wide march), 2048 in all (deep march)
-  static size_t segsPerRay(int lanes) { return lanes <= 4 ? size_t(lanes) * kWideSegCap : size_t(2048); }
+  int wideMode = 1;                     // option wide_march: 0 off, 1 by cost, 2 / 4 every tile with that many lanes (tests)
+  // listed leaves per ray of a wide tile: kWideSegCap per window
+  static size_t segsPerRay(int lanes) { return size_t(lanes) * kWideSegCap; }
   int numSimdWaves = 256 * 4 * 6;       // waves the device holds at the march kernel's occupancy
   DevBuf<int32_t> normalMap, wideMap;   // one-lane tiles in launch order; wide tiles, the 4-lane ones first
   DevBuf<float4> wideSegs;              // leaf lists of the wide march's window walkers (grown on demand)
@@ -536,10 +535,9 @@ struct ExaHipRenderer {
   {
     const size_t n = curMap.size();
     std::vector<int32_t> normal, w4, w2;
-    int lanesTop = topLanes;
-    if (wideMode == 2 || wideMode == 4 || wideMode == 8 || wideMode == 16) {
+    const int lanesTop = 4;
+    if (wideMode == 2 || wideMode == 4) {
       (wideMode >= 4 ? w4 : w2) = curMap;
-      if (wideMode >= 4) lanesTop = wideMode;
     } else if (wideMode == 1 && costOfTile) {
       // Model constants: a critical tile finishes kSpeed2 (2 lanes) times sooner and costs kWork2 / kWork4
       // times the work; a loaded GPU steps a wave 1.3x slower.  Measured with the round-1 kernels (probe 6.0 -> 3.7 ->
@@ -551,7 +549,7 @@ struct ExaHipRenderer {
       // streams that carry one frame's launches share a hardware queue, and the shard of 8 went from 4.6 to 7.0 ms.
       double kSpeed2 = EXA_WIDE_SPEED2;
       const double kWork2 = EXA_WIDE_WORK2, kLoaded = 1.3;
-      double kWork4 = lanesTop > 4 ? EXA_DEEP_WORK : EXA_WIDE_WORK4;
+      double kWork4 = EXA_WIDE_WORK4;
       if (const char *e = std::getenv("EXA_WIDE_WORK_TOP")) kWork4 = std::atof(e);          // calibration runs
       if (const char *e = std::getenv("EXA_WIDE_SPEED2")) kSpeed2 = std::atof(e);
       double fill = 0;
@@ -704,13 +702,23 @@ struct ExaHipRenderer {
     if (needLbvh() && ensureLbvh()) return 1;
     if (applyBrickOrder(s)) return 1;
     {
-      const int want = (useKd() && interleave && p.numPrimaryChannels >= 2 && p.numPrimaryChannels <= 4) ? p.numPrimaryChannels : 0;
+      int want = (useKd() && interleave && p.numPrimaryChannels >= 2 && p.numPrimaryChannels <= 4) ? p.numPrimaryChannels : 0;
+      if (want == ilNoMemory) want = 0;                    // this many channels did not fit before: field by field
       if (want != ilChannels) {
         HIP_TRY(this, hipStreamSynchronize(s));            // frames in flight may still read the old copy
         cellsIl.release();
         ilChannels = 0;
+        if (want && cellsIl.alloc(size_t(totalCells) * want + 2 * size_t(want)) != hipSuccess) {      // a pair load may reach one cell past the end
+          // the copy is an optimisation (want x one field of extra memory): without it the march reads the fields one after
+          // the other, same pixels
+          (void)hipGetLastError();
+          cellsIl.release();
+          if (std::getenv("EXA_HIP_VERBOSE"))
+            std::fprintf(stderr, "[exa_hip] no memory for the channel-interleaved copy of %d fields: field-by-field march\n", want);
+          ilNoMemory = want;
+          want = 0;
+        }
         if (want) {
-          HIP_TRY(this, cellsIl.alloc(size_t(totalCells) * want + 2 * size_t(want)));     // a pair load may reach one cell past the end
           HIP_TRY(this, hipMemsetAsync(cellsIl.p + size_t(totalCells) * want, 0, 2 * size_t(want) * sizeof(float), s));
           HIP_TRY(this, launchInterleave(sc, totalCells, want, cellsIl.p, s));
           ilChannels = want;
@@ -877,7 +885,7 @@ struct ExaHipRenderer {
     if (haveTracer && tracer.enabled && timestep < tracer.numTimesteps && timestep >= 1) {
       // computeTraces: the threads with pixelIdx < numTraces (exabrick.cu:1539)
       const long long px = (long long)W * H;
-      HIP_TRY(this, launchComputeTraces(a, traces.p, (int)std::min<long long>(tracer.numTraces, px), s));
+      HIP_TRY(this, EXA_FORM(launchComputeTraces)(a, traces.p, (int)std::min<long long>(tracer.numTraces, px), s));
     }
     if (useKd() && surfacesEnabled() && surf.n != accum.n) {
       HIP_TRY(this, surf.alloc(accum.n));
@@ -886,7 +894,11 @@ struct ExaHipRenderer {
     }
     a.aoRecs = nullptr; a.aoCount = nullptr;
     if (useKd() && surfacesEnabled() && fs.ao.enabled && aoDefer && !stats) {
-      if (aoRecs.n != accum.n) HIP_TRY(this, aoRecs.alloc(accum.n));
+      // one record per pixel of every launched tile, the padding pixels of partial edge tiles included: the heavy
+      // pipeline's list starts behind nPreCheap WHOLE tiles (accum.n = W * H on one GPU is smaller when W or H is not a
+      // multiple of the tile)
+      const size_t recs = size_t(numBlocks) * kTilePixels;
+      if (aoRecs.n != recs) HIP_TRY(this, aoRecs.alloc(recs));
       if (!aoCount.p) HIP_TRY(this, aoCount.alloc(8));        // per pipeline: [0] listed hits, [2] the AO kernel's chunk counter
       HIP_TRY(this, hipMemsetAsync(aoCount.p, 0, 8 * sizeof(uint32_t), s));
       a.aoRecs = aoRecs.p; a.aoCount = aoCount.p;
@@ -908,19 +920,19 @@ struct ExaHipRenderer {
           ah.aoCount = a.aoCount + 4;
         }
         HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
-        HIP_TRY(this, launchSurfacePrepassKd(ah, nPreHeavy, false, side2));
+        HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(ah, nPreHeavy, false, side2));
         HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
-        HIP_TRY(this, launchSurfacePrepassKd(ac, nPreCheap, false, sideN));
-        HIP_TRY(this, launchRenderKd(ac, nPreCheap, p.gradientShadingDVR != 0, fastMath != 0, true, 0, sideN));
+        HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(ac, nPreCheap, false, sideN));
+        HIP_TRY(this, EXA_FORM(launchRenderKd)(ac, nPreCheap, p.gradientShadingDVR != 0, fastMath != 0, true, 0, sideN));
         HIP_TRY(this, hipEventRecord(evJoinN, sideN));
-        HIP_TRY(this, launchRenderKd(ah, nPreHeavy, p.gradientShadingDVR != 0, fastMath != 0, true, 0, side2));
+        HIP_TRY(this, EXA_FORM(launchRenderKd)(ah, nPreHeavy, p.gradientShadingDVR != 0, fastMath != 0, true, 0, side2));
         HIP_TRY(this, hipEventRecord(evJoin2, side2));
         HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
         HIP_TRY(this, hipStreamWaitEvent(s, evJoinN, 0));
       } else {
-      if (surfOn) HIP_TRY(this, launchSurfacePrepassKd(a, numBlocks, stats, s));
+      if (surfOn) HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(a, numBlocks, stats, s));
       if (!wide) {
-        HIP_TRY(this, launchRenderKd(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats ? statsMode : 0, s));
+        HIP_TRY(this, EXA_FORM(launchRenderKd)(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats ? statsMode : 0, s));
       } else {
         // the critical tiles on side streams so that they start together with the rest of the frame
         HIP_TRY(this, hipEventRecord(evFork, s));
@@ -929,14 +941,14 @@ struct ExaHipRenderer {
           HIP_TRY(this, hipStreamWaitEvent(side4, evFork, 0));
           aw.wideTileMap = wideMap.p;
           aw.wideSegs = wideSegs.p;
-          HIP_TRY(this, launchRenderKdWide(aw, nWide4, lanesTopInUse, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side4));
+          HIP_TRY(this, EXA_FORM(launchRenderKdWide)(aw, nWide4, lanesTopInUse, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side4));
           HIP_TRY(this, hipEventRecord(evJoin4, side4));
         }
         if (nWide2) {
           HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
           aw.wideTileMap = wideMap.p + nWide4;
           aw.wideSegs = wideSegs.p + size_t(nWide4) * segsPerRay(lanesTopInUse) * kTilePixels;
-          HIP_TRY(this, launchRenderKdWide(aw, nWide2, 2, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side2));
+          HIP_TRY(this, EXA_FORM(launchRenderKdWide)(aw, nWide2, 2, p.gradientShadingDVR != 0, fastMath != 0, surfOn, side2));
           HIP_TRY(this, hipEventRecord(evJoin2, side2));
         }
         // the rest of the frame on a stream of its own as well: launched on the caller's stream it would not
@@ -944,7 +956,7 @@ struct ExaHipRenderer {
         RenderArgs an = a;
         an.tileMap = normalMap.p;
         HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
-        HIP_TRY(this, launchRenderKd(an, nNormal, p.gradientShadingDVR != 0, fastMath != 0, surfOn, false, sideN));
+        HIP_TRY(this, EXA_FORM(launchRenderKd)(an, nNormal, p.gradientShadingDVR != 0, fastMath != 0, surfOn, false, sideN));
         HIP_TRY(this, hipEventRecord(evJoinN, sideN));
         if (nWide4) HIP_TRY(this, hipStreamWaitEvent(s, evJoin4, 0));
         if (nWide2) HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
@@ -952,7 +964,7 @@ struct ExaHipRenderer {
       }
       }
     }
-    else         HIP_TRY(this, launchRender(a, numBlocks, p.gradientShadingDVR != 0, surfacesEnabled(), stats, s));
+    else         HIP_TRY(this, EXA_FORM(launchRender)(a, numBlocks, p.gradientShadingDVR != 0, surfacesEnabled(), stats, s));
     last.node_bytes = useKd() ? sizeof(KdNodeDev) : sizeof(BvhNode);
     HIP_TRY(this, hipEventRecord(ev1, s));
     return 0;
@@ -1028,9 +1040,25 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
       h->beginMorton[keyed[i].second] = uint32_t(at);
       at += uint64_t(B.size[0]) * uint64_t(B.size[1]) * uint64_t(B.size[2]);
     }
-    // bricks that share cells or leave gaps (nothing the reference's loader produces) keep the uploaded order
-    if (at != scene->totalCells) h->beginMorton = h->beginUploaded;
-    if (const char *e = std::getenv("EXA_BRICK_ORDER")) h->brickOrderWanted = std::atoi(e) != 0;
+    // The permutation moves field f at f * totalCells and brick b's cells as one block [begin, begin + volume): it needs the
+    // layout the reference's constructor produces (OptixRenderer.cpp:71-110) — channel offsets f * totalCells and the
+    // uploaded begins a partition of [0, totalCells) into the bricks' volumes.  Anything else keeps the uploaded order.
+    bool partition = at == scene->totalCells;
+    for (int f = 0; f < scene->numFields && partition; f++) partition = scene->channelOffset[f] == uint64_t(f) * scene->totalCells;
+    if (partition) {
+      std::vector<std::pair<uint32_t, uint64_t>> spans(nb);                  // (begin, volume), sorted by begin
+      for (uint64_t b = 0; b < nb; b++) {
+        const ExaBrick &B = scene->bricks[b];
+        spans[b] = { B.begin, uint64_t(B.size[0]) * uint64_t(B.size[1]) * uint64_t(B.size[2]) };
+      }
+      std::sort(spans.begin(), spans.end());
+      uint64_t run = 0;
+      for (uint64_t b = 0; b < nb && partition; b++) { partition = spans[b].first == run; run += spans[b].second; }
+    }
+    h->brickOrderPossible = partition;
+    if (!partition) h->beginMorton = h->beginUploaded;
+    if (const char *e = std::getenv("EXA_BRICK_ORDER")) h->brickOrderWanted = std::atoi(e) != 0 && h->brickOrderPossible;
+    if (const char *e = std::getenv("EXA_BASIS_FORM")) h->basisForm = std::atoi(e) != 0;    // initial value of option basis_form
   }
   for (int k = 0; k < 3; k++) { h->voxLo[k] = scene->voxelBounds_lo[k]; h->voxHi[k] = scene->voxelBounds_hi[k]; }
   static_assert(sizeof(ExaBrick) == 2 * sizeof(int4), "brick = two int4");
@@ -1519,12 +1547,8 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "tile_order")) { h->tileOrder = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "tile_feedback")) { h->feedback = value; h->layoutDirty = true; return 0; }
   if (!std::strcmp(key, "wide_march")) {
-    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16) { h->fail("exa_hip_set_option: wide_march is 0, 1, 2, 4, 8 or 16"); return 1; }
+    if (value != 0 && value != 1 && value != 2 && value != 4) { h->fail("exa_hip_set_option: wide_march is 0, 1, 2 or 4"); return 1; }
     h->wideMode = value; h->layoutDirty = true; return 0;
-  }
-  if (!std::strcmp(key, "wide_top")) {
-    if (value != 4 && value != 8 && value != 16) { h->fail("exa_hip_set_option: wide_top is 4, 8 or 16"); return 1; }
-    h->topLanes = value; h->layoutDirty = true; return 0;
   }
   if (!std::strcmp(key, "stats_mode")) {
     if (value != 1 && value != 2) { h->fail("exa_hip_set_option: stats_mode is 1 or 2"); return 1; }
@@ -1534,6 +1558,11 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "prepass_split")) { h->prepassSplit = value != 0; h->costPhase = 1; return 0; }
   if (!std::strcmp(key, "walk_probe")) { h->walkProbeOn = value != 0; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
+  if (!std::strcmp(key, "profile_marker")) {            // an empty kernel on the null stream, visible in a profiler's dispatch list
+    EXA_ON_DEVICE(h);
+    if (launchProfileMarker(value, nullptr) != hipSuccess) { h->fail("exa_hip_set_option: profile_marker launch failed"); return 1; }
+    return 0;
+  }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
   if (!std::strcmp(key, "lbvh_build")) {              // 0 = on the device (default), 1 = on the host; before the first LBVH frame
     if (h->lbvhBuilt && value != h->lbvhOnHost) { h->fail("exa_hip_set_option: lbvh_build must be set before the LBVH is first used"); return 1; }
@@ -1541,9 +1570,19 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   }
   if (!std::strcmp(key, "fast_math")) { h->fastMath = value; return 0; }
   if (!std::strcmp(key, "fast_sampler")) { h->fastSampler = value; return 0; }
+  if (!std::strcmp(key, "basis_form")) {
+    if (value != 0 && value != 1) { h->fail("exa_hip_set_option: basis_form is 0 or 1"); return 1; }
+    h->basisForm = value; return 0;
+  }
   if (!std::strcmp(key, "interleave")) { h->interleave = value != 0; return 0; }
   if (!std::strcmp(key, "addr64")) { h->addr64 = value != 0; return 0; }
-  if (!std::strcmp(key, "brick_order")) { h->brickOrderWanted = value != 0; return 0; }
+  if (!std::strcmp(key, "brick_order")) {
+    if (value && !h->brickOrderPossible) {
+      h->fail("exa_hip_set_option: brick_order 1 needs channel offsets f * totalCells and brick begins that partition [0, totalCells)");
+      return 1;
+    }
+    h->brickOrderWanted = value != 0; return 0;
+  }
   if (!std::strcmp(key, "tf_filter")) {
     if (value != 0 && value != 1) { h->fail("exa_hip_set_option: tf_filter is 0 or 1"); return 1; }
     if (value != h->tfFilter) { h->tfFilter = value; h->volDirty = true; }     // region activity goes through the TF lookup

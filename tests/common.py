@@ -31,8 +31,15 @@ class Case:
     def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
                  space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
                  xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None, contour=None, meshes=None,
-                 tf_filter=None):
+                 tf_filter=None, basis_form=None):
         self.scene, self.W, self.H = scene, W, H
+        # association of the eight-corner basis sums on BOTH sides (oracle: or_set_basis_form, module: option basis_form):
+        # 0 = the reference's source order, 1 = per axis with fused multiply-adds; None = the module's default, which the
+        # oracle (whose own default is the source order) is then told to follow (EXA_TEST_BASIS_FORM runs a whole test
+        # session in one form)
+        env = os.environ.get("EXA_TEST_BASIS_FORM")
+        from owlexabrick_amd.binding import DEFAULT_BASIS_FORM
+        self.basis_form = basis_form if basis_form is not None else (int(env) if env else DEFAULT_BASIS_FORM)
         self.grad, self.iso, self.dt = grad, iso, dt
         self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
         self.opacity_scale, self.space_skipping = opacity_scale, space_skipping
@@ -70,6 +77,8 @@ class Case:
             S.set_xf(c, xf)
         if self.tf_filter is not None:
             S.set_tf_filter(self.tf_filter)
+        if self.basis_form is not None:
+            S.set_basis_form(self.basis_form)
         if self.meshes:
             S.set_triangles(*self._merged_meshes())
         return S
@@ -116,6 +125,8 @@ class Case:
             R.setOption("fast_math", self.fast_math)
         if self.tf_filter is not None:
             R.setOption("tf_filter", self.tf_filter)
+        if self.basis_form is not None:
+            R.setOption("basis_form", self.basis_form)
         for k, v in getattr(self, "options", {}).items():
             R.setOption(k, v)
         lo, hi = prep.voxel_bounds()

@@ -15,11 +15,12 @@ from owlexabrick_amd import scenes
 from test_oracle_kat import _hat_reconstruction
 
 
-def check(seed):
+def check(seed, basis_form=0):
     rng = np.random.default_rng(0x04AC1E00 + seed)
     grids, ext = _random_grids(rng)
     sc = scenes.artificial(grids, name=f"grids{seed}")
     S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    S.set_basis_form(basis_form)
     R, LL = S.regions(), S.leaflist()
     bad = []
     # (a) hat basis

@@ -45,6 +45,13 @@ GOLDEN_CASES = {
     # default camera / TF / dt, gradient shading off and on; the fixture holds the centre 192x192 crop of the frame
     "c1_64_512": ("c1_64", dict(W=512, H=512, window=(160, 160, 352, 352))),
     "c1_64_512_grad": ("c1_64", dict(W=512, H=512, grad=1, window=(160, 160, 352, 352))),
+    # Everything above is rendered with the basis sums in the reference's source order (basis_form = 0, pinned in
+    # make_case).  The per-axis association the kernels ship by default (basis_form = 1) has its own fixtures:
+    "ex3_grad_pa": ("ex3", dict(W=64, H=48, grad=1, basis_form=1)),
+    "ex3_iso_pa": ("ex3", dict(W=64, H=48, grad=1, iso=[(0.4, 0)], basis_form=1)),
+    "ex4_grad_iso2_pa": ("ex4", dict(W=64, H=48, grad=1, iso=[(0.3, 0), (0.7, 0)], basis_form=1)),
+    "ex4_accum3_pa": ("ex4", dict(W=64, H=48, grad=1, frames=3, basis_form=1)),
+    "c1_64_512_grad_pa": ("c1_64", dict(W=512, H=512, grad=1, window=(160, 160, 352, 352), basis_form=1)),
 }
 
 
@@ -53,6 +60,7 @@ def make_case(name):
     kw = dict(kw)
     frames = kw.pop("frames", 1)
     kw.pop("window", None)
+    kw.setdefault("basis_form", 0)
     if kw.get("xf") == "band":
         kw["xf"] = band_xf()
     return Case(scenes.example(scn), **kw), frames

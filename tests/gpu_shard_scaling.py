@@ -9,8 +9,6 @@ sc = scenes.config("c4_exajet", scale=float(sys.argv[1]) if len(sys.argv) > 1 el
 case = Case(sc, W=2048, H=2048, grad=1, xf_domains=[(0.0, 1.0)])
 R = case.hip_renderer()
 opts = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [4]
-if len(sys.argv) > 3:                      # lanes per ray of the top wide class (4 = wide march, 8 / 16 = deep march)
-    R.setOption("wide_top", int(sys.argv[3]))
 for order in opts:
     R.setOption("tile_order", order)
     base = None

@@ -11,7 +11,7 @@ R = case.hip_renderer()
 shards = int(sys.argv[2]) if len(sys.argv) > 2 else 64      # 64: 256 tiles (one round of workgroups at 4 lanes per ray); 256: 64 tiles (one round at 16)
 R.setShard(0, shards)
 ref = None
-for lanes in (0, 2, 4, 8, 16):
+for lanes in (0, 2, 4):
     R.setOption("wide_march", lanes)
     R.setOption("tile_feedback", 0)
     img = R.render()
@@ -29,7 +29,7 @@ R.resizeFrameBuffer((1024, 1024))
 cam = __import__("owlexabrick_amd.harness", fromlist=["x"]).default_camera(*R.voxelSpaceBounds, 1024, 1024)
 R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
 base = None
-for lanes in (0, 2, 4, 8, 16):
+for lanes in (0, 2, 4):
     R.setOption("wide_march", lanes)
     R.render(); R.render()
     t = []

@@ -1,0 +1,103 @@
+"""The two associations of the eight-corner basis sums of addBasisFunctions (exabrick.cu:620-777), CPU side.
+
+form 0 = the reference's source order (oracle: add_basis_functions), the definition.
+form 1 = the same sums per axis, x-pairs -> y -> z, with fused multiply-adds (add_basis_functions_factored): what the
+         kernels ship (binding.DEFAULT_BASIS_FORM).  The reference BINARY computes neither sequence literally (nvcc
+         contracts a*b+c by default, CMakeLists.txt passes no -fmad=false), so both are restatements of one real-valued
+         expression; these tests hold form 1 to form 0 under the tolerance of tests/common.py and to the definition of the
+         basis, and count — not hide — the pixels that move.  (GPU == oracle in either form: tests/test_gpu_parity.py.)"""
+import numpy as np
+import pytest
+
+from common import ACCUM_ATOL, ACCUM_RTOL, Case, band_xf, compare, po
+from owlexabrick_amd import scenes
+
+
+FORM_ATOL = 1e-3     # form 1 vs form 0, accumulation buffer, every pixel (see the first test)
+
+
+def _amr():
+    return scenes.amr(seed=3, root=(3, 3, 2), B=4, levels=3)
+
+
+FORM_CASES = {
+    "ex2": lambda f: Case(scenes.example("ex2"), W=96, H=64, basis_form=f),
+    "ex3_grad": lambda f: Case(scenes.example("ex3"), W=96, H=64, grad=1, basis_form=f),
+    "ex4_grad": lambda f: Case(scenes.example("ex4"), W=96, H=64, grad=1, basis_form=f),
+    "c1_64_grad": lambda f: Case(scenes.example("c1_64"), W=128, H=128, grad=1, basis_form=f),
+    "amr": lambda f: Case(_amr(), W=128, H=128, basis_form=f),
+    "amr_grad": lambda f: Case(_amr(), W=128, H=128, grad=1, basis_form=f),
+    "amr_band": lambda f: Case(_amr(), W=128, H=128, xf=band_xf(), basis_form=f),
+    "amr_inside": lambda f: Case(_amr(), W=96, H=96, grad=1, camera=([20.3, 22.1, 14.2], [30, 20, 10], [0, 1, 0], 80.0), basis_form=f),
+    "amr_2ch": lambda f: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2), W=128, H=128, grad=1,
+                              basis_form=f),
+    "gen_exajet": lambda f: Case(scenes.generated(kind="exajet", seed=11, root=(4, 2, 2), B=8, levels=3), W=160, H=96, grad=1,
+                                 basis_form=f),
+}
+
+
+@pytest.mark.parametrize("name", sorted(FORM_CASES))
+def test_per_axis_form_equals_source_order_within_the_stated_tolerance(name):
+    """DVR frames (with and without gradient shading) in both forms.  STATED TOLERANCE of form 1 against form 0:
+    |d accum| <= FORM_ATOL = 1e-3 for every pixel and RGBA8 <= 1 LSB; at most 1 % of the pixels beyond the CPU-vs-GPU
+    tolerance of tests/common.py (2e-5 + 1e-4 |accum|); same number of samples up to rays whose termination moves.
+    Measured on these cases: without gradient shading <= 1e-4 (an ulp of a sample's value in front of the quantised TF
+    filter weight); with gradient shading up to 3.1e-4 on 0.3 % of the pixels (amr_2ch: 47 of 16 384) — samples in
+    nearly flat neighbourhoods, where the gradient sumW * sumD - sumWV * sumDC is the rounding noise of either
+    association and the |cos| shading factor of a sample whose |g| sits at the 1e-6 threshold is arbitrary in both.
+    The count is printed (pytest -s), not hidden."""
+    o0, o1 = FORM_CASES[name](0).run_oracle(), FORM_CASES[name](1).run_oracle()
+    r = compare(o0, o1, name)
+    npx = o0[1].shape[0] * o0[1].shape[1]
+    assert r["accum_max"] <= FORM_ATOL and r["rgba_max"] <= 1 and r["flip_pixels"] <= 0.01 * npx, r
+    for k in ("samples", "brick_visits", "segments"):
+        assert abs(o0[2][k] - o1[2][k]) <= 1e-3 * o0[2][k] + 2, (k, o0[2][k], o1[2][k])
+    print(f"{name}: pixels beyond the CPU-vs-GPU tolerance {r['flip_pixels']} of {npx}, max |d accum| {r['accum_max']:.3g}, "
+          f"RGBA8 pixels differing {r['rgba_diff_px']} (max {r['rgba_max']} LSB)")
+
+
+@pytest.mark.parametrize("name", ["ex3_iso", "amr_iso", "amr_2ch_iso"])
+def test_per_axis_form_iso_surfaces(name):
+    """implicit iso-surfaces: the hit point is found by bracketing, so an ulp in a value can move a crossing by a step
+    for a rare pixel; the surface colour of such a pixel changes like an AO flip (<= 0.3 % of the pixels)"""
+    mk = {"ex3_iso": lambda f: Case(scenes.example("ex3"), W=96, H=64, grad=1, iso=[(0.4, 0)], basis_form=f),
+          "amr_iso": lambda f: Case(_amr(), W=128, H=128, grad=1, iso=[(0.45, 0)], basis_form=f),
+          "amr_2ch_iso": lambda f: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2), W=96, H=96,
+                                        grad=1, iso=[(0.35, 1), (0.65, 1)], basis_form=f)}[name]
+    o0, o1 = mk(0).run_oracle(), mk(1).run_oracle()
+    da = np.abs(o0[1] - o1[1]).max(axis=-1)
+    moved = int((da > ACCUM_ATOL + ACCUM_RTOL * np.abs(o0[1]).max(axis=-1)).sum())
+    assert moved <= max(2, 0.003 * da.size), (moved, float(da.max()))
+    assert o0[2]["iso_segments"] == o1[2]["iso_segments"]
+    print(f"{name}: pixels beyond tolerance {moved} of {da.size}, max |d accum| {float(da.max()):.3g}")
+
+
+def test_constant_neighbourhood_has_exactly_zero_gradient_in_the_per_axis_form():
+    """KAT: on a constant field the per-axis form's derivative sums cancel exactly inside a brick (d = -c + c, the y and
+    z differences of equal partial sums), where the source order leaves the rounding noise of 8 sequential additions;
+    the value is the constant in both (up to an ulp of the weight sum)"""
+    big = scenes.artificial([[0, 0, 0, 8, 8, 8, 0] + [0.7] * 8], name="const8")
+    for scn in (big,):
+        n0 = 0
+        for form in (0, 1):
+            S = po.OracleScene(scn.bricks7, scn.cellIDs, scn.fields)
+            S.set_basis_form(form)
+            lo, hi = S.voxel_bounds()
+            rng = np.random.default_rng(5)
+            for p in rng.uniform(np.asarray(lo) + 0.6, np.asarray(hi) - 0.6, size=(200, 3)):
+                ok, v, g = S.sample_point(0, p.astype(np.float32), with_derivative=True)
+                assert ok and abs(float(v) - float(scn.fields[0][0])) <= 2e-7
+                if form == 1:
+                    assert not np.any(g), (p, g)
+                else:
+                    n0 += int(np.any(g))
+        if scn is big:
+            assert n0 > 0        # the source order does leave noise there (what gradient shading then normalises)
+
+
+def test_both_forms_count_the_same_cells():
+    """corner_loads / brick_visits of one frame are equal in both forms when no ray flips (same positions, same in-brick
+    tests: the forms differ in the order of additions only)"""
+    c0, c1 = Case(scenes.example("ex2"), W=64, H=48, basis_form=0), Case(scenes.example("ex2"), W=64, H=48, basis_form=1)
+    s0, s1 = c0.run_oracle()[2], c1.run_oracle()[2]
+    assert s0 == s1

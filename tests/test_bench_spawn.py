@@ -56,12 +56,15 @@ def test_pmc_frame_totals_sum_the_kernels_of_a_frame(tmp_path):
     spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    shipped = "void exa::renderFrameKdKernel<true, true, 0, false, 0, true, 0>(exa::RenderArgs)"
-    counted = "void exa::renderFrameKdKernel<true, true, 0, false, 1, false, 0>(exa::RenderArgs)"
-    il3 = "void exa::renderFrameKdKernel<true, true, 2, false, 0, true, 3>(exa::RenderArgs)"
+    shipped = "void exa::form1::renderFrameKdKernel<true, true, 0, false, 0, true, 0>(exa::RenderArgs)"
+    counted = "void exa::form1::renderFrameKdKernel<true, true, 0, false, 1, false, 0>(exa::RenderArgs)"
+    il3 = "void exa::form0::renderFrameKdKernel<true, true, 2, false, 0, true, 3>(exa::RenderArgs)"
     assert all(re.search(bench.FRAME_KERNELS["march"], k) for k in (shipped, il3)) and not re.search(bench.FRAME_KERNELS["march"], counted)
-    wide = "void exa::renderFrameKdWideKernel<true, true, false, 4, true>(exa::RenderArgs)"
-    pre = "void exa::surfacePrepassKdKernel<0, true>(exa::RenderArgs)"
+    wide = "void exa::form1::renderFrameKdWideKernel<true, true, false, 4, true>(exa::RenderArgs)"
+    pre = "void exa::form1::surfacePrepassKdKernel<0, true, false>(exa::RenderArgs)"
+    pre_counted = "void exa::form1::surfacePrepassKdKernel<1, false, false>(exa::RenderArgs)"
+    ao = "void exa::form1::aoRaysKdKernel<true>(exa::RenderArgs)"
+    assert re.search(bench.FRAME_KERNELS["surfaces_prepass"], pre) and not re.search(bench.FRAME_KERNELS["surfaces_prepass"], pre_counted)
     rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Kernel_Name,Counter_Name,Counter_Value"]
     rows += [f'1,1,0,"{counted}",FETCH_SIZE,1000.0']
     rows += [f'2,2,0,"{shipped}",FETCH_SIZE,10.0', f'2,2,0,"{shipped}",FETCH_SIZE,30.0']       # two instances
@@ -74,7 +77,23 @@ def test_pmc_frame_totals_sum_the_kernels_of_a_frame(tmp_path):
     assert frames == 2
     assert tot == {"march": {"FETCH_SIZE": 50.0, "WRITE_SIZE": 2.5}, "march_wide": {"FETCH_SIZE": 4.0},
                    "surfaces_prepass": {"FETCH_SIZE": 3.0}}
-    lbvh = "void exa::renderFrameKernel<true, true, 0>(exa::RenderArgs)"
+    # a run bracketed by two marker dispatches: only what lies between them counts, divided by the number of frames the
+    # run says it put there — here 2 frames of the split pre-pass plan: two pre-pass and two march dispatches per frame
+    # plus one AO launch; warm-up frames in front of the first marker and the counting frame behind the second are left out
+    mark = "void exa::profileMarkerKernel(int)"
+    rows = [rows[0], f'1,1,0,"{shipped}",SQ_INSTS_VALU,999.0', f'2,2,0,"{mark}",SQ_INSTS_VALU,1.0']
+    did = 3
+    for frame in range(2):
+        for k, v in ((pre, 1.0), (pre, 2.0), (shipped, 10.0), (shipped, 20.0), (ao, 4.0)):
+            rows.append(f'{did},{did},0,"{k}",SQ_INSTS_VALU,{v}')
+            did += 1
+    rows += [f'{did},{did},0,"{mark}",SQ_INSTS_VALU,1.0', f'{did + 1},{did + 1},0,"{counted}",SQ_INSTS_VALU,777.0',
+             f'{did + 2},{did + 2},0,"{shipped}",SQ_INSTS_VALU,888.0']
+    f.write_text("\n".join(rows) + "\n")
+    tot, frames = bench.pmc_frame_totals([str(f)], frames=2)
+    assert frames == 2 and tot == {"march": {"SQ_INSTS_VALU": 30.0}, "surfaces_prepass": {"SQ_INSTS_VALU": 3.0},
+                                   "ao_rays": {"SQ_INSTS_VALU": 4.0}}
+    lbvh = "void exa::form1::renderFrameKernel<true, true, 0>(exa::RenderArgs)"
     f.write_text(rows[0] + f'\n1,1,0,"{lbvh}",SQ_INSTS_VALU,3.0\n')
     assert bench.pmc_frame_totals([str(f)]) == ({"march": {"SQ_INSTS_VALU": 3.0}}, 1)
     assert bench.pmc_frame_totals([]) == ({}, 0)

@@ -104,10 +104,13 @@ def test_brick_order_in_memory_does_not_change_the_frame(nf):
     R.close()
 
 
-def test_prepass_split_launch_plan_does_not_change_the_frame():
-    """option prepass_split: heavy pre-pass tiles in their own pre-pass + march pipeline beside the rest of the frame"""
+@pytest.mark.parametrize("size", [(320, 256), (312, 250)], ids=["whole_tiles", "ragged_edge_tiles"])
+def test_prepass_split_launch_plan_does_not_change_the_frame(size):
+    """option prepass_split: heavy pre-pass tiles in their own pre-pass + march pipeline beside the rest of the frame
+    (ragged: W and H not multiples of the 16-pixel tile — the heavy pipeline's deferred-AO list then starts behind the
+    padded pixels of the cheap pipeline's edge tiles)"""
     sc = scenes.config("c3_gear", scale=0.2)
-    kw = dict(W=320, H=256, grad=1, iso=[(0.5, 0)], ao=1, ao_length=200.0, xf_domains=[(0.0, 1.0)] * len(sc.fields))
+    kw = dict(W=size[0], H=size[1], grad=1, iso=[(0.5, 0)], ao=1, ao_length=200.0, xf_domains=[(0.0, 1.0)] * len(sc.fields))
     outs = {}
     for split in (0, 1, 2):                      # 2: the split plan with the AO rays traced inline
         case = Case(sc, **kw)

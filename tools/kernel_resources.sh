@@ -1,11 +1,11 @@
 #!/bin/bash
-# Registers / scratch / LDS of the kernels in csrc/exa_kernels.o (gfx950 code object), optionally filtered by a regex.
+# Registers / scratch / LDS of the kernels in csrc/exa_kernels_f0.o (EXA_FORM=1: _f1.o; gfx950 code object), optionally filtered by a regex.
 # usage: tools/kernel_resources.sh [regex]   (run after `make -C owlexabrick_amd/csrc`)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TMP=$(mktemp -d)
 cd "$TMP"
-cp "$ROOT/owlexabrick_amd/csrc/exa_kernels.o" k.o          # the bundles are extracted next to the input
+cp "$ROOT/owlexabrick_amd/csrc/exa_kernels_f${EXA_FORM:-0}.o" k.o          # EXA_FORM=1: the per-axis association
 /opt/rocm/lib/llvm/bin/llvm-objdump --offloading k.o > /dev/null
 CO=$(ls | grep gfx950)
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes "$CO" | grep -E "^\s+\.name:|\.vgpr_count|\.sgpr_count|private_segment_fixed_size|\.group_segment_fixed_size|vgpr_spill" \
