@@ -6,8 +6,9 @@
   C4  exajet-like, full  2048x2048 DVR                      (the bench line's workload)
   C5  exajet-like, full  4096x4096 DVR + iso-surface + AO, frames 0..15 accumulated
 
-For each: (a) the oracle on a 96x96 crop where the rays are dense and on one across the silhouette, under the
-tolerance of tests/common.py; (b) properties that need no oracle at full size: the kd walk and the LBVH restart pick
+For each: (a) the oracle under the tolerance of tests/common.py — on the WHOLE frame for C2, C3 and C4 (every pixel
+of the 1024^2 / 2048^2 frame; 16 host threads render them in about 2 / 20 / 30 s), on a 96x96 crop where the rays are
+dense and on one across the silhouette for C5 (16 accumulated 4096^2 frames); (b) properties that need no oracle at full size: the kd walk and the LBVH restart pick
 the same segments (bit-equal frames with the library powf), space skipping is image-neutral (KAT-7), launch order,
 launch-order feedback and the wide march never change a pixel (also as rank 0 of 8, where the wide march engages)."""
 import numpy as np
@@ -143,11 +144,24 @@ def _oracle_crops(cfg, base_acc, frames=1, ao=0, what=""):
     return wins
 
 
+def _oracle_whole_frame(cfg, base_acc, what):
+    """every pixel of the frame against the oracle (same tolerance as the crops: termination flips only)"""
+    import time
+    W, H = cfg.case.W, cfg.case.H
+    t = time.time()
+    acc = cfg.oracle_frames((0, 0, W, H))
+    print(f"{what}: oracle rendered the whole {W}x{H} frame in {time.time() - t:.1f}s")
+    _check_crop(base_acc, acc, (0, 0, W, H), 1, 0, f"{what} whole frame")
+    d = np.abs(base_acc.astype(np.float64) - acc.astype(np.float64)).max(axis=-1)
+    print(f"{what}: max |d accum| {d.max():.3g}, pixels beyond 2e-5 + 1e-4 |accum|: "
+          f"{int((np.abs(base_acc.astype(np.float64) - acc) > ACCUM_ATOL + ACCUM_RTOL * np.abs(acc)).any(axis=-1).sum())} of {W * H}")
+
+
 def test_c2_lanl_1024_dvr():
     cfg = Config("c2_lanl", 1024)
     try:
         base = _properties(cfg)
-        _oracle_crops(cfg, base[1], what="C2")
+        _oracle_whole_frame(cfg, base[1], "C2")
     finally:
         cfg.close()
 
@@ -157,7 +171,7 @@ def test_c3_gear_2048_dvr_two_channels_plus_iso():
     try:
         assert cfg.R.params.numPrimaryChannels == 2
         base = _properties(cfg)
-        _oracle_crops(cfg, base[1], what="C3")
+        _oracle_whole_frame(cfg, base[1], "C3")
     finally:
         cfg.close()
 
@@ -195,7 +209,7 @@ def test_c4_exajet_full_2048_dvr(exajet_full):
     cfg = exajet_full(2048)
     assert cfg.sc.num_cells > 6e8
     base = _properties(cfg)
-    _oracle_crops(cfg, base[1], what="C4")
+    _oracle_whole_frame(cfg, base[1], "C4")
 
 
 def test_c5_exajet_full_4096_dvr_iso_ao_16_frames(exajet_full):
