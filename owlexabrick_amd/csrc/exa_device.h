@@ -59,6 +59,9 @@
 #ifndef EXA_OPT_RSQ
 #define EXA_OPT_RSQ 1         // fast_math: gradient-shading factor with one transcendental (rsq) instead of three (sqrt, sqrt, rcp)
 #endif
+#ifndef EXA_OPT_LANE_MORTON
+#define EXA_OPT_LANE_MORTON 1 // lanes of a wave cover their 8x8 pixel block along a Morton curve (quad = 2x2 pixels) instead of row by row
+#endif
 #ifndef EXA_BASIS_FORM
 #define EXA_BASIS_FORM 0      // which association of the basis sums this translation unit of exa_kernels.hip is compiled for
 #endif

@@ -106,6 +106,19 @@ __device__ __forceinline__ float clockHeat(float clockScale, unsigned long long 
 }
 struct Color4 { float x, y, z, w; };
 
+// lane -> pixel inside the wave's 8x8 block.  EXA_OPT_LANE_MORTON: along a Morton curve, so that a quad of lanes is a 2x2
+// pixel block and 16 lanes a 4x4 block instead of 4x1 / 8x2 strips: the vector memory path handles a wave's gather
+// lane group by lane group and merges the lanes of a group that fall into the same cache line, and the march is bound by
+// the number of such accesses (TCP_TOTAL_CACHE_ACCESSES = one per clock and CU over the whole frame) —
+// closer pixels share more lines.  Pixels do not depend on which lane renders them.
+#if EXA_OPT_LANE_MORTON
+__device__ __forceinline__ int laneX(int lane) { return (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4); }
+__device__ __forceinline__ int laneY(int lane) { return ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4); }
+#else
+__device__ __forceinline__ int laneX(int lane) { return lane & 7; }
+__device__ __forceinline__ int laneY(int lane) { return lane >> 3; }
+#endif
+
 // per-thread view of the kernel state.  STATS: 0 = the shipped kernel, 1 = work counters (sample for sample the
 // oracle's), 2 = wave time by phase only (the shipped code plus a clock read at every phase change)
 template <int STATS>
@@ -1302,7 +1315,7 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
   const int tile = a.tileMap[blockIdx.x];
   const int tx = tile % a.tilesX, ty = tile / a.tilesX;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
+  const int inX = ((wave & 1) << 3) + laneX(lane), inY = ((wave >> 1) << 3) + laneY(lane);
   const int px = tx * kTile + inX, py = ty * kTile + inY;
   const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
 
@@ -1783,7 +1796,7 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
   const int tile = a.tileMap[gwave >> 2];
   const int tx = tile % a.tilesX, ty = tile / a.tilesX;
   const int wave = gwave & 3, lane = threadIdx.x & 63;
-  const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
+  const int inX = ((wave & 1) << 3) + laneX(lane), inY = ((wave >> 1) << 3) + laneY(lane);
   const int px = tx * kTile + inX, py = ty * kTile + inY;
   const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
 
@@ -2007,7 +2020,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
   const int tile = a.tileMap[gwave >> 2];
   const int tx = tile % a.tilesX, ty = tile / a.tilesX;
   const int wave = gwave & 3, lane = threadIdx.x & 63;
-  const int inX = ((wave & 1) << 3) + (lane & 7), inY = ((wave >> 1) << 3) + (lane >> 3);
+  const int inX = ((wave & 1) << 3) + laneX(lane), inY = ((wave >> 1) << 3) + laneY(lane);
   const int px = tx * kTile + inX, py = ty * kTile + inY;
   const bool inside = px < a.W && py < a.H && (a.debugPixel < 0 || a.debugPixel == px + a.W * py);
 
@@ -2258,7 +2271,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       unsigned tid = threadIdx.x;
       asm volatile("" : "+v"(tid));
       const int lane2 = tid & 63, wave2 = (tid >> 6) & 3;
-      const int inX2 = ((wave2 & 1) << 3) + (lane2 & 7), inY2 = ((wave2 >> 1) << 3) + (lane2 >> 3);
+      const int inX2 = ((wave2 & 1) << 3) + laneX(lane2), inY2 = ((wave2 >> 1) << 3) + laneY(lane2);
       slot = (a.world == 1) ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2)
                             : size_t(tile / a.world) * kTilePixels + (inY2 * kTile + inX2);
       colorSlot = a.colorRowMajor ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2) : slot;
