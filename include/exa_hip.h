@@ -103,7 +103,15 @@ typedef struct ExaHipScene {
   const ExaKdNode      *kdNodes;       /* optional (may be NULL) */
   uint64_t              numKdNodes;
   int32_t               kdRoot;        /* reference of the root (a leaf ref for a one-region scene) */
+  int32_t               allowEmptyCells; /* the reference's compile-time option ALLOW_EMPTY_CELLS (CMakeLists.txt:70-73, default
+                                          OFF) as a property of the scene: scalars equal to EXA_EMPTY_CELL_POISON_VALUE are
+                                          "no cell here" and addBasisFunctions skips them (programs/exabrick.cu:614-618) */
 } ExaHipScene;
+
+/* programs/FrameState.h:27 */
+#define EXA_EMPTY_CELL_POISON_VALUE (-1e20f)
+/* exa_prep_create_ex flags */
+#define EXA_PREP_ALLOW_EMPTY_CELLS 1   /* cell id -1 = no cell: its slot holds the poison value (exa/OptixRenderer.cpp:116-118) */
 
 /* work counters of one frame (instrumented kernel variant); the basis of the
  * algorithmic-bytes figure in DESIGN.md */
@@ -153,6 +161,14 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
                     const float *const *fields, const uint64_t *fieldLen,
                     int32_t numFields, int32_t numRegionFields, int32_t numThreads,
                     ExaPrep **out);
+/* as exa_prep_create with `flags` (EXA_PREP_*).  EXA_PREP_ALLOW_EMPTY_CELLS = the reference built with
+ * -DALLOW_EMPTY_CELLS=1: negative cell ids other than -1 stay an error; the regions' value ranges include the poison
+ * value, as the reference's computeValueRange (exa/Regions.cpp:182-240) does; the scene is marked allowEmptyCells */
+int exa_prep_create_ex(const int32_t *bricks7, uint64_t numBricks,
+                       const int32_t *cellIDs, uint64_t numCellIDs,
+                       const float *const *fields, const uint64_t *fieldLen,
+                       int32_t numFields, int32_t numRegionFields, int32_t numThreads, int32_t flags,
+                       ExaPrep **out);
 void exa_prep_destroy(ExaPrep *);
 /* fills an ExaHipScene whose pointers stay valid until exa_prep_destroy */
 int  exa_prep_scene(const ExaPrep *, ExaHipScene *out);

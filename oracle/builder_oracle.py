@@ -67,7 +67,7 @@ def all_ids_without_duplicate_cells(cells):           # :301-350
     return out
 
 
-def build_bricks(cells, builder_type=SAH_ALIKE, max_leaf_width=127):
+def build_bricks(cells, builder_type=SAH_ALIKE, max_leaf_width=127, allow_empty_cells=False):
     """returns [(size3, lower3, level, cellIDs[flat])] in the reference's output order"""
     cells = np.asarray(cells, dtype=np.int64).reshape(-1, 4)
     bricks = []
@@ -77,20 +77,24 @@ def build_bricks(cells, builder_type=SAH_ALIKE, max_leaf_width=127):
         b = Box4()
         for i in ids:
             b.extend(cell_bounds(cells[i]))
+        tight = Box4(); tight.lo, tight.hi = list(b.lo), list(b.hi)        # ALLOW_EMPTY_CELLS: leaf bounds from its cells (:483-495)
         cw = 1 << (b.hi[3] - 1)
         for d in range(3):
             b.lo[d] = cw * div_down(b.lo[d], cw)
             b.hi[d] = cw * div_up(b.hi[d], cw)
         # tryMakeLeaf :447-530
         if (b.size(3) <= 1 and all(b.size(d) // cw <= max_leaf_width for d in range(3))
-                and b.size(0) * b.size(1) * b.size(2) * b.size(3) == len(ids) * cw ** 3):
+                and (allow_empty_cells          # ALLOW_EMPTY_CELLS: no volume test (:473-481), holes keep -1
+                     or b.size(0) * b.size(1) * b.size(2) * b.size(3) == len(ids) * cw ** 3)):
+            if allow_empty_cells:
+                b = tight
             sz = [b.size(d) // cw for d in range(3)]
             arr = [-1] * (sz[0] * sz[1] * sz[2])
             for i in ids:
                 c = cells[i]
                 idx = [(int(c[d]) - b.lo[d]) // cw for d in range(3)]
                 arr[idx[0] + sz[0] * (idx[1] + sz[1] * idx[2])] = i
-            assert -1 not in arr
+            assert allow_empty_cells or -1 not in arr
             bricks.append((sz, b.lo[:3], b.lo[3], arr))
             return
         dims = [b.size(d) // cw for d in range(3)]

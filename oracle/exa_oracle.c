@@ -106,6 +106,8 @@ struct OrScene {
   KdNode   *nodes; size_t numNodes, capNodes;
   float     xf[OR_MAX_CHANNELS][OR_NUM_XF_VALUES][4];
   float     tfFracMagic;   /* 32768: filter fraction held in 1.8 fixed point (CUDA tex1D); 0: full precision */
+  int       allowEmptyCells; /* the reference's compile-time option ALLOW_EMPTY_CELLS (CMakeLists.txt:70, default OFF): cell id -1 =
+                                no cell; its slot holds EMPTY_CELL_POISON_VALUE and addBasisFunctions skips it */
   int       basisForm;     /* 0: addBasisFunctions in the reference's source order (the definition, default);
                               1: the same eight-corner sums associated per axis, x -> y -> z, with fused multiply-adds */
   float    *meshVerts; int32_t *meshTris; size_t numVerts, numTris;   /* all surfaces, concatenated */
@@ -280,6 +282,16 @@ OrScene *or_scene_create(const int32_t *bricks7, size_t numBricks,
                          const float *const *fields, const size_t *fieldLen,
                          int numFields, int numRegionFields,
                          char *err, size_t errLen)
+{ return or_scene_create_ex(bricks7, numBricks, cellIDs, numCellIDs, fields, fieldLen, numFields, numRegionFields, 0, err, errLen); }
+
+/* programs/FrameState.h:27 */
+#define EMPTY_CELL_POISON_VALUE -1e20f
+
+OrScene *or_scene_create_ex(const int32_t *bricks7, size_t numBricks,
+                            const int32_t *cellIDs, size_t numCellIDs,
+                            const float *const *fields, const size_t *fieldLen,
+                            int numFields, int numRegionFields, int allowEmptyCells,
+                            char *err, size_t errLen)
 {
 #define FAIL(msg) do { if (err && errLen) snprintf(err, errLen, "%s", msg); or_scene_destroy(S); return NULL; } while (0)
   OrScene *S = (OrScene *)calloc(1, sizeof(OrScene));
@@ -287,6 +299,7 @@ OrScene *or_scene_create(const int32_t *bricks7, size_t numBricks,
   S->numBricks = numBricks;
   S->numFields = numFields;
   S->tfFracMagic = 32768.f;           /* default: the published CUDA linear filter */
+  S->allowEmptyCells = allowEmptyCells != 0;
   S->bricks = (OrBrick *)xmalloc(numBricks * sizeof(OrBrick));
   /* exa/OptixRenderer.cpp:75-93 flatten */
   size_t scalarOffset = 0;
@@ -319,7 +332,11 @@ OrScene *or_scene_create(const int32_t *bricks7, size_t numBricks,
     float *dst = S->scalars + S->offsets[f];
     for (size_t i = 0; i < S->totalCells; i++) {
       int32_t cellID = cellIDs[i];
-      if (cellID < 0) FAIL("overflow in index vector...");       /* :116-120 */
+      if (cellID < 0) {                                           /* :116-121 */
+        if (!S->allowEmptyCells) FAIL("overflow in index vector...");
+        dst[i] = EMPTY_CELL_POISON_VALUE;                         /* ALLOW_EMPTY_CELLS: :117-118 */
+        continue;
+      }
       if ((size_t)cellID >= fieldLen[f]) FAIL("invalid cell ID"); /* :125-126 */
       dst[i] = fields[f][cellID];
     }
@@ -414,7 +431,9 @@ void or_set_xf(OrScene *S, int chan, const float *rgba128)
 /* 1 (default): the tex1D filter weight in 9-bit fixed point with 8 fractional bits, as the CUDA C
  * programming guide publishes it; 0: full-precision weight */
 void or_set_tf_filter(OrScene *S, int cudaFixedPoint) { S->tfFracMagic = cudaFixedPoint ? 32768.f : 0.f; }
-void or_set_basis_form(OrScene *S, int form) { S->basisForm = form ? 1 : 0; }
+/* the per-axis association needs "this corner counts" to be a product of per-axis predicates; an empty cell is not, so a
+ * scene with empty cells keeps the source order */
+void or_set_basis_form(OrScene *S, int form) { S->basisForm = (form && !S->allowEmptyCells) ? 1 : 0; }
 
 /* ------------------------------------------------------------------ */
 /* pixel helpers                                                       */
@@ -681,6 +700,7 @@ static void add_basis_functions(Ctx *C, Basis *B, int need_derivative, int brick
 #define CORNER(IX, IY, IZ, WZ, WY, WX, SDX, SDY, SDZ)                                        \
   do {                                                                                       \
     const float scalar = get_scalar(C, brick, IX, IY, IZ, channel);                          \
+    if (C->S->allowEmptyCells && !(scalar != EMPTY_CELL_POISON_VALUE)) break;   /* notEmptyCell, :614-618, :646 ... */ \
     const float weight = (WZ) * (WY) * (WX);                                                 \
     if (need_derivative) {                                                                   \
       const float dx = (WZ) * (WY) * (SDX 1.f);                                              \

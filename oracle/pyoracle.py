@@ -82,6 +82,8 @@ def lib():
         vp, sz, fp, ip = C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_int32)
         L.or_scene_create.restype = vp
         L.or_scene_create.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.c_int, C.c_int, C.c_char_p, sz]
+        L.or_scene_create_ex.restype = vp
+        L.or_scene_create_ex.argtypes = [vp, sz, vp, sz, C.POINTER(vp), C.POINTER(sz), C.c_int, C.c_int, C.c_int, C.c_char_p, sz]
         L.or_scene_destroy.argtypes = [vp]
         for n in ("or_num_bricks", "or_num_regions", "or_leaflist_size", "or_total_cells"):
             getattr(L, n).restype = sz
@@ -130,7 +132,7 @@ def _f3(v):
 class OracleScene:
     """OptixRenderer ctor data prep + ExaBrickRegions::buildFrom, restated on the CPU."""
 
-    def __init__(self, bricks7, cellIDs, fields, num_region_fields=None):
+    def __init__(self, bricks7, cellIDs, fields, num_region_fields=None, allow_empty_cells=False):
         L = lib()
         self.bricks7 = np.ascontiguousarray(bricks7, dtype=np.int32).reshape(-1, 7)
         self.cellIDs = np.ascontiguousarray(cellIDs, dtype=np.int32)
@@ -141,9 +143,9 @@ class OracleScene:
         ptrs = (C.c_void_p * max(nf, 1))(*[f.ctypes.data for f in self.fields])
         lens = (C.c_size_t * max(nf, 1))(*[f.size for f in self.fields])
         err = C.create_string_buffer(256)
-        self.h = L.or_scene_create(self.bricks7.ctypes.data, self.bricks7.shape[0],
-                                   self.cellIDs.ctypes.data, self.cellIDs.size,
-                                   ptrs, lens, nf, num_region_fields, err, 256)
+        self.h = L.or_scene_create_ex(self.bricks7.ctypes.data, self.bricks7.shape[0],
+                                      self.cellIDs.ctypes.data, self.cellIDs.size,
+                                      ptrs, lens, nf, num_region_fields, int(bool(allow_empty_cells)), err, 256)
         if not self.h:
             raise RuntimeError(err.value.decode())
         self.num_fields = nf

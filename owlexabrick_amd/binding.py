@@ -64,7 +64,7 @@ class ExaHipScene(C.Structure):
                 ("scalars", C.c_void_p), ("channelOffset", C.c_void_p),
                 ("totalCells", C.c_uint64), ("numFields", C.c_int32),
                 ("voxelBounds_lo", C.c_float * 3), ("voxelBounds_hi", C.c_float * 3),
-                ("kdNodes", C.c_void_p), ("numKdNodes", C.c_uint64), ("kdRoot", C.c_int32)]
+                ("kdNodes", C.c_void_p), ("numKdNodes", C.c_uint64), ("kdRoot", C.c_int32), ("allowEmptyCells", C.c_int32)]
 
 
 class ExaHipStats(C.Structure):
@@ -89,7 +89,7 @@ KDNODE_DTYPE = np.dtype([("split", "<f4"), ("axis", "<i4"), ("left", "<i4"), ("r
 KD_EMPTY = -2 ** 31
 
 # every symbol include/exa_hip.h declares
-ABI_SYMBOLS = ["exa_prep_create", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error",
+ABI_SYMBOLS = ["exa_prep_create", "exa_prep_create_ex", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error",
                "exa_hip_create", "exa_hip_create_multi", "exa_hip_destroy", "exa_hip_resize", "exa_hip_set_frame_state",
                "exa_hip_set_xf", "exa_hip_set_triangles", "exa_hip_reset_tracer", "exa_hip_set_tracer_enabled",
                "exa_hip_advance_tracer", "exa_hip_read_traces", "exa_hip_set_params", "exa_hip_set_shard", "exa_hip_output_pixels",
@@ -117,6 +117,9 @@ def lib():
         L.exa_prep_create.restype = C.c_int
         L.exa_prep_create.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64),
                                       C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+        L.exa_prep_create_ex.restype = C.c_int
+        L.exa_prep_create_ex.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64),
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
         L.exa_prep_destroy.argtypes = [vp]
         L.exa_prep_scene.argtypes = [vp, C.POINTER(ExaHipScene)]
         L.exa_prep_last_error.restype = C.c_char_p
@@ -152,7 +155,8 @@ def lib():
 class Prep:
     """host data preparation of the OptixRenderer constructor (exa_prep_*)."""
 
-    def __init__(self, scene, num_region_fields=None, num_threads=0):
+    def __init__(self, scene, num_region_fields=None, num_threads=0, allow_empty_cells=False):
+        """allow_empty_cells: the reference's build option ALLOW_EMPTY_CELLS (cell id -1 = no cell, EXA_PREP_ALLOW_EMPTY_CELLS)"""
         L = lib()
         self.bricks7 = np.ascontiguousarray(scene.bricks7, dtype=np.int32).reshape(-1, 7)
         self.cellIDs = np.ascontiguousarray(scene.cellIDs, dtype=np.int32)
@@ -161,9 +165,10 @@ class Prep:
         ptrs = (C.c_void_p * max(nf, 1))(*[f.ctypes.data for f in self.fields])
         lens = (C.c_uint64 * max(nf, 1))(*[f.size for f in self.fields])
         self.h = C.c_void_p()
-        rc = L.exa_prep_create(self.bricks7.ctypes.data, self.bricks7.shape[0], self.cellIDs.ctypes.data,
-                               self.cellIDs.size, ptrs, lens, nf,
-                               nf if num_region_fields is None else num_region_fields, num_threads, C.byref(self.h))
+        rc = L.exa_prep_create_ex(self.bricks7.ctypes.data, self.bricks7.shape[0], self.cellIDs.ctypes.data,
+                                  self.cellIDs.size, ptrs, lens, nf,
+                                  nf if num_region_fields is None else num_region_fields, num_threads,
+                                  1 if allow_empty_cells else 0, C.byref(self.h))
         if rc:
             raise RuntimeError(L.exa_prep_last_error().decode())
         self.scene = ExaHipScene()

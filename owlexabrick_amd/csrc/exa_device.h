@@ -62,6 +62,9 @@
 #ifndef EXA_OPT_LANE_MORTON
 #define EXA_OPT_LANE_MORTON 1 // lanes of a wave cover their 8x8 pixel block along a Morton curve (quad = 2x2 pixels) instead of row by row
 #endif
+#ifndef EXA_EMPTY_CELLS
+#define EXA_EMPTY_CELLS 0     // this translation unit of exa_kernels.hip skips corners whose cell holds the poison value
+#endif
 #ifndef EXA_BASIS_FORM
 #define EXA_BASIS_FORM 0      // which association of the basis sums this translation unit of exa_kernels.hip is compiled for
 #endif
@@ -237,6 +240,10 @@ hipError_t buildLbvhTopologyDevice(const float *boxes, uint32_t numPrims, BvhNod
   hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hipStream_t s);
 namespace form0 { EXA_FORM_LAUNCHERS }
 namespace form1 { EXA_FORM_LAUNCHERS }
+// ... and once more in the source order with the reference's ALLOW_EMPTY_CELLS semantics (-DEXA_EMPTY_CELLS=1: a corner whose
+// cell holds EXA_EMPTY_CELL_POISON_VALUE is skipped, exabrick.cu:614-618), for scenes marked allowEmptyCells
+// (exa_kernels_f0e.o; no interleaved and no wide march there)
+namespace form0e { EXA_FORM_LAUNCHERS }
 #undef EXA_FORM_LAUNCHERS
 
 // ---- kernels that never sample (compiled once, with form 0) ----

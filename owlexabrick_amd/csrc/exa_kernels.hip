@@ -18,8 +18,12 @@
 //           of the cell index is done on the float
 //   DTPOW2  first sample of a segment: x / dt as x * (1/dt) when dt is a power of two (exact)
 //   MED3    clamp(l, 0, size-1) as one v_med3_i32
-#if EXA_BASIS_FORM == 0
+#if EXA_BASIS_FORM == 0 && EXA_EMPTY_CELLS
+#define EXA_FORM_NS form0e
+#elif EXA_BASIS_FORM == 0
 #define EXA_FORM_NS form0
+#elif EXA_BASIS_FORM == 1 && EXA_EMPTY_CELLS
+#error "empty cells are a per-corner property: the per-axis association (EXA_BASIS_FORM 1) does not apply"
 #elif EXA_BASIS_FORM == 1
 #define EXA_FORM_NS form1
 #else
@@ -332,7 +336,9 @@ __device__ __forceinline__ void addBasisFunctions(Ctx<STATS> &C, Basis &B, const
   C.count(ST_BRICK_VISITS);
 #define EXA_CORNER(VALID, S, WZ, WY, WX, SGX, SGY, SGZ)                                     \
   {                                                                                          \
-    const bool v_ = (VALID);                                                                 \
+    /* EXA_EMPTY_CELLS: notEmptyCell(scalar), exabrick.cu:614-618, 646 ...; the cell is read (and counted) either way */ \
+    const bool v_ = (VALID) && (!EXA_EMPTY_CELLS || (S) != EXA_EMPTY_CELL_POISON_VALUE);     \
+    if (STATS == 1 && (VALID)) C.st[ST_CORNER_LOADS]++;                                      \
     const float w_ = (WZ) * (WY) * (WX);                                                     \
     if (DERIV) {                                                                             \
       const float dx_ = (WZ) * (WY) * (SGX 1.f);                                             \
@@ -347,7 +353,6 @@ __device__ __forceinline__ void addBasisFunctions(Ctx<STATS> &C, Basis &B, const
     }                                                                                        \
     B.sumW = v_ ? B.sumW + w_ : B.sumW;                                                      \
     B.sumWV = v_ ? B.sumWV + w_ * (S) : B.sumWV;                                             \
-    if (STATS == 1 && v_) C.st[ST_CORNER_LOADS]++;                                                \
   }
   // corner order of the reference: z-lo{y-lo{x-lo,x-hi}, y-hi{..}}, z-hi{..}
   EXA_CORNER(vlz && vly && vlx, s000, nz, ny, nx, -, -, -)   // :644-658
@@ -515,8 +520,12 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
     // bit (an fma rounds once, and there is nothing to round in zy * mx), and `sum += dx_ * s` equals
     // fma(zy * s, mx, sum): (+-zy) * s rounds to +-(zy * s), and for mx = 0 both forms add a zero of the sign of s.
     // 13 instructions per corner instead of 16.
-#define EXA_ACC(S, ZY, WX, MX, ZX, MY, YX, MZ)                                               \
+    // EXA_EMPTY_CELLS: a corner whose cell holds the poison value is skipped (notEmptyCell, exabrick.cu:614-618): its three
+    // pair weights are zeroed, so every term it adds is a zero (the poison value is finite)
+#define EXA_ACC(S, ZY0, WX, MX, ZX0, MY, YX0, MZ)                                            \
     {                                                                                        \
+      const bool ne_ = !EXA_EMPTY_CELLS || (S) != EXA_EMPTY_CELL_POISON_VALUE;               \
+      const float ZY = ne_ ? (ZY0) : 0.f, ZX = ne_ ? (ZX0) : 0.f, YX = ne_ ? (YX0) : 0.f;    \
       B.sumDC.x = __builtin_fmaf((ZY), (MX), B.sumDC.x);                                     \
       B.sumDC.y = __builtin_fmaf((ZX), (MY), B.sumDC.y);                                     \
       B.sumDC.z = __builtin_fmaf((YX), (MZ), B.sumDC.z);                                     \
@@ -536,7 +545,7 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
     EXA_ACC(s111, zyHH, wxh, mxh, zxHH, myh, yxHH, mzh)
 #undef EXA_ACC
   } else {
-#define EXA_ACC(S, ZY, WX) { const float w_ = (ZY) * (WX); B.sumW += w_; B.sumWV += w_ * (S); }
+#define EXA_ACC(S, ZY, WX) { const float w_ = (!EXA_EMPTY_CELLS || (S) != EXA_EMPTY_CELL_POISON_VALUE) ? (ZY) * (WX) : 0.f; B.sumW += w_; B.sumWV += w_ * (S); }
     EXA_ACC(s000, zyLL, wxl) EXA_ACC(s100, zyLL, wxh) EXA_ACC(s010, zyLH, wxl) EXA_ACC(s110, zyLH, wxh)
     EXA_ACC(s001, zyHL, wxl) EXA_ACC(s101, zyHL, wxh) EXA_ACC(s011, zyHH, wxl) EXA_ACC(s111, zyHH, wxh)
 #undef EXA_ACC
@@ -2682,6 +2691,9 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
 hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s)
 {
   if (numTiles <= 0) return hipSuccess;
+#if EXA_EMPTY_CELLS
+  return hipErrorNotSupported;       // scenes with empty cells march one lane per ray (the module never asks for more)
+#else
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
   const dim3 grid(numTiles * lanesPerRay), block(kKdBlock);
   const bool small = a.mul24 && a.addr32;                   // 24-bit address multiplies and 32-bit byte offsets are valid
@@ -2697,6 +2709,7 @@ hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay
 #undef EXA_W2
 #undef EXA_W3
   return hipGetLastError();
+#endif
 }
 
 hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s)
@@ -2734,7 +2747,7 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
   // The instrumented variants exist for 0 and 2 only.
   const int mode = a.p.numPrimaryChannels > 1 ? ((a.numXfChannels <= 2 && !stats) ? 1 : 2) : 0;
   // interleaved march: the module has built float[cell][numPrimaryChannels] (a.cellsIl); shipped kernel only
-  const int nch = (a.cellsIl && !stats && a.p.numPrimaryChannels >= 2 && a.p.numPrimaryChannels <= 4) ? a.p.numPrimaryChannels : 0;
+  const int nch = (!EXA_EMPTY_CELLS && a.cellsIl && !stats && a.p.numPrimaryChannels >= 2 && a.p.numPrimaryChannels <= 4) ? a.p.numPrimaryChannels : 0;
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4)
                    + size_t((mode == 1 && !nch ? kKdStackMulti : kKdStack) + kSegQueue) * kKdBlock * 12 + EXA_LDS_PAD;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
@@ -2745,6 +2758,7 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
                                    else if (small) EXA_LAUNCH(G, F, M, I, 0, true); else EXA_LAUNCH(G, F, M, I, 0, false); } while (0)
 #define EXA_PICK(G, F, M) do { if (surf) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
 #define EXA_PICKM(G, F) do { if (mode == 0) EXA_PICK(G, F, 0); else if (mode == 1) EXA_PICK(G, F, 1); else EXA_PICK(G, F, 2); } while (0)
+#if !EXA_EMPTY_CELLS
   if (nch) {
     // LDS: nch TF tables + a 4-entry stack + the queue = 28 / 30 / 32 KB per workgroup (5 workgroups per CU)
     const bool smallIl = small && a.il32;
@@ -2760,6 +2774,7 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
 #undef EXA_IL4
     return hipGetLastError();
   }
+#endif
   if (grad) { if (fast) EXA_PICKM(true, true); else EXA_PICKM(true, false); }
   else      { if (fast) EXA_PICKM(false, true); else EXA_PICKM(false, false); }
 #undef EXA_PICKM
@@ -2771,7 +2786,7 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
 
 } // namespace EXA_FORM_NS
 
-#if EXA_BASIS_FORM == 0     // kernels that never sample are compiled once
+#if EXA_BASIS_FORM == 0 && !EXA_EMPTY_CELLS     // kernels that never sample are compiled once
 using namespace form0;
 // kd activity bits, one height class per launch (children before parents)
 __global__ __launch_bounds__(256) void kdRefitKernel(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count,
@@ -2869,7 +2884,7 @@ hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hi
 
 } // namespace EXA_FORM_NS
 
-#if EXA_BASIS_FORM == 0
+#if EXA_BASIS_FORM == 0 && !EXA_EMPTY_CELLS
 // ------------------------------------------------------------------------
 // Region activity: the OPTIX_BOUNDS_PROGRAMs (exabrick.cu:250-312, 373-402)
 // ------------------------------------------------------------------------
@@ -3066,5 +3081,5 @@ hipError_t launchProfileMarker(int tag, hipStream_t s)
   hipLaunchKernelGGL(profileMarkerKernel, dim3(1), dim3(1), 0, s, tag);
   return hipGetLastError();
 }
-#endif // EXA_BASIS_FORM == 0
+#endif // EXA_BASIS_FORM == 0 && !EXA_EMPTY_CELLS
 } // namespace exa

@@ -30,7 +30,7 @@ using namespace exa;
 #endif
 
 // the launchers of the sampling kernels exist once per association of the basis sums (exa_device.h)
-#define EXA_FORM(fn) (basisForm ? form1::fn : form0::fn)
+#define EXA_FORM(fn) (emptyCells ? form0e::fn : (basisForm ? form1::fn : form0::fn))
 
 namespace {
 
@@ -221,6 +221,7 @@ struct ExaHipRenderer {
   int ilChannels = 0;
   int ilNoMemory = 0;                // channel count whose interleaved copy could not be allocated (not tried again)
   int interleave = 1;                // option "interleave"
+ bool emptyCells = false;           // the scene is marked allowEmptyCells (the reference's ALLOW_EMPTY_CELLS build): source-order kernels with the poison test
   int basisForm = 1;                 // option "basis_form": 1 (default) = the eight-corner basis sums per axis with fused multiply-adds, 0 = in the reference's source order
   int addr64 = 0;                    // option "addr64": the general 64-bit address form even where 32-bit offsets would do (tests)
   uint64_t totalCells = 0;
@@ -702,7 +703,7 @@ struct ExaHipRenderer {
     if (needLbvh() && ensureLbvh()) return 1;
     if (applyBrickOrder(s)) return 1;
     {
-      int want = (useKd() && interleave && p.numPrimaryChannels >= 2 && p.numPrimaryChannels <= 4) ? p.numPrimaryChannels : 0;
+      int want = (useKd() && interleave && !emptyCells && p.numPrimaryChannels >= 2 && p.numPrimaryChannels <= 4) ? p.numPrimaryChannels : 0;
       if (want == ilNoMemory) want = 0;                    // this many channels did not fit before: field by field
       if (want != ilChannels) {
         HIP_TRY(this, hipStreamSynchronize(s));            // frames in flight may still read the old copy
@@ -906,7 +907,7 @@ struct ExaHipRenderer {
     HIP_TRY(this, hipEventRecord(ev0, s));
     if (useKd()) {
       const bool surfOn = surfacesEnabled();
-      const bool wide = !stats && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
+      const bool wide = !stats && !emptyCells && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
       const bool split = surfOn && !stats && !wide && costPhase == 0 && !a.tileCost && nPreHeavy > 0 && nPreCheap > 0
                          && nPreHeavy + nPreCheap == numBlocks && a.debugPixel < 0;
       if (split) {
@@ -1010,6 +1011,8 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
     if (scene->channelOffset[f] + scene->totalCells > uint64_t(scene->numFields) * scene->totalCells) { h->fail("exa_hip_create: channel offset out of range"); return bail(); }
 
   h->numFields = scene->numFields;
+  h->emptyCells = scene->allowEmptyCells != 0;
+  if (h->emptyCells) h->basisForm = 0;
   h->totalCells = scene->totalCells;
   h->numBricks = scene->numBricks; h->leafListSize = scene->leafListSize;
   {
@@ -1058,7 +1061,7 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
     h->brickOrderPossible = partition;
     if (!partition) h->beginMorton = h->beginUploaded;
     if (const char *e = std::getenv("EXA_BRICK_ORDER")) h->brickOrderWanted = std::atoi(e) != 0 && h->brickOrderPossible;
-    if (const char *e = std::getenv("EXA_BASIS_FORM")) h->basisForm = std::atoi(e) != 0;    // initial value of option basis_form
+    if (const char *e = std::getenv("EXA_BASIS_FORM")) h->basisForm = std::atoi(e) != 0 && !h->emptyCells;    // initial value of option basis_form
   }
   for (int k = 0; k < 3; k++) { h->voxLo[k] = scene->voxelBounds_lo[k]; h->voxHi[k] = scene->voxelBounds_hi[k]; }
   static_assert(sizeof(ExaBrick) == 2 * sizeof(int4), "brick = two int4");
@@ -1572,6 +1575,10 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   if (!std::strcmp(key, "fast_sampler")) { h->fastSampler = value; return 0; }
   if (!std::strcmp(key, "basis_form")) {
     if (value != 0 && value != 1) { h->fail("exa_hip_set_option: basis_form is 0 or 1"); return 1; }
+    if (value && h->emptyCells) {
+      h->fail("exa_hip_set_option: a scene with empty cells keeps basis_form 0 (an empty cell is a per-corner property, the per-axis association needs per-axis ones)");
+      return 1;
+    }
     h->basisForm = value; return 0;
   }
   if (!std::strcmp(key, "interleave")) { h->interleave = value != 0; return 0; }

@@ -195,6 +195,7 @@ struct ExaPrep {
   std::vector<uint64_t>       channelOffset;
   uint64_t totalCells = 0;
   int32_t  numFields = 0;
+  int32_t  allowEmptyCells = 0;
   float    boundsLo[3], boundsHi[3];
 };
 
@@ -250,6 +251,13 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
                     const float *const *fields, const uint64_t *fieldLen,
                     int32_t numFields, int32_t numRegionFields, int32_t numThreads,
                     ExaPrep **out)
+{ return exa_prep_create_ex(bricks7, numBricks, cellIDs, numCellIDs, fields, fieldLen, numFields, numRegionFields, numThreads, 0, out); }
+
+int exa_prep_create_ex(const int32_t *bricks7, uint64_t numBricks,
+                       const int32_t *cellIDs, uint64_t numCellIDs,
+                       const float *const *fields, const uint64_t *fieldLen,
+                       int32_t numFields, int32_t numRegionFields, int32_t numThreads, int32_t flags,
+                       ExaPrep **out)
 {
   if (!out) return 1;
   *out = nullptr;
@@ -265,6 +273,8 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
   // ---- flatten (exa/OptixRenderer.cpp:71-93) ----
   P->bricks.resize(numBricks);
   P->numFields = numFields;
+  P->allowEmptyCells = (flags & EXA_PREP_ALLOW_EMPTY_CELLS) ? 1 : 0;
+  const bool allowEmpty = P->allowEmptyCells != 0;
   for (int k = 0; k < 3; k++) { P->boundsLo[k] = INFINITY; P->boundsHi[k] = -INFINITY; }
   uint64_t running = 0;
   for (uint64_t i = 0; i < numBricks; i++) {
@@ -298,7 +308,11 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
     parallelChunks(P->totalCells, numThreads, [&](size_t b, size_t e) {
       for (size_t i = b; i < e; i++) {
         const int32_t id = cellIDs[i];
-        if (id < 0) { bad = 1; continue; }
+        if (id < 0) {
+          // ALLOW_EMPTY_CELLS (exa/OptixRenderer.cpp:116-121; the loader admits -1 only, exa/ExaBricks.cpp:46-49)
+          if (allowEmpty && id == -1) dst[i] = EXA_EMPTY_CELL_POISON_VALUE; else bad = 1;
+          continue;
+        }
         if (uint64_t(id) >= len) { bad = 2; continue; }
         dst[i] = src[id];
       }
@@ -362,6 +376,7 @@ int exa_prep_scene(const ExaPrep *P, ExaHipScene *out)
   out->kdNodes = P->kdNodes.data();
   out->numKdNodes = P->kdNodes.size();
   out->kdRoot = P->kdRoot;
+  out->allowEmptyCells = P->allowEmptyCells;
   for (int k = 0; k < 3; k++) { out->voxelBounds_lo[k] = P->boundsLo[k]; out->voxelBounds_hi[k] = P->boundsHi[k]; }
   return 0;
 }

@@ -8,6 +8,7 @@
 //             [--gradientShadingDVR 0|1] [--gradientShadingISO 0|1] [--frames N] [-o out.ppm] [--info] [--stats]
 //             [--gpus N | --devices 0,1,..]  one renderer over several GPUs (tiles dealt round-robin, stored straight into
 //                                            the first device's frame); a device may be listed more than once
+//             [--allow-empty-cells]          cell id -1 in the .bricks file = no cell (the reference's ALLOW_EMPTY_CELLS build)
 //             [--pipeline]                   frames go to two device buffers in turn, frame k's copy to the host overlaps
 //                                            frame k+1's march
 #include "exa_host.h"
@@ -59,6 +60,7 @@ int main(int argc, char **argv)
     int frames = 1;
     std::vector<int> devices;
     bool pipeline = false;
+    bool allowEmptyCells = false;
     std::vector<float> contourPlanes;                             // 4 floats per --contourplane (normal, offset)
     std::vector<int> contourChans;
     for (int i = 1; i < argc; i++) {
@@ -101,12 +103,14 @@ int main(int argc, char **argv)
         if (devices.empty()) throw std::runtime_error("--devices wants a comma-separated list of device indices");
       }
       else if (a == "--pipeline") pipeline = true;
+      else if (a == "--allow-empty-cells") allowEmptyCells = true;    // the reference built with -DALLOW_EMPTY_CELLS=1
       else if (a[0] != '-') cfgName = a;
       else throw std::runtime_error("unknown flag " + a);
     }
     if (cfgName.empty()) throw std::runtime_error("usage: exaRender cfg.exa [flags]");
     Config::SP config = Config::parseConfigFile(cfgName);
     if (!config->bricks.sp) throw std::runtime_error("no bricks file specified");
+    config->bricks.sp->allowEmptyCells = allowEmptyCells;
     const box3f bounds = config->getBounds();
     std::printf("bricks %zu cells %zu fields %zu\n", config->bricks.sp->numBricks(), config->bricks.sp->totalNumCells,
                 config->scalarFields.size());

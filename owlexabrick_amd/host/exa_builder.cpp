@@ -59,6 +59,7 @@ struct Builder {
   const std::vector<Cell> &cells;
   std::vector<int32_t> ids;
   int type, maxLeafWidth;
+  bool allowEmptyCells = false;   // the reference's build option ALLOW_EMPTY_CELLS (builder.cpp:473-495), here --allow-empty-cells
   bool verbose;
   std::vector<int32_t> bricks7, brickCells;       // output, `.bricks` order
 
@@ -111,14 +112,16 @@ struct Builder {
     // coarse-aligned bounds of this cell set (computeCoarsestLevelBounds, :185-215)
     Box4 b;
     for (size_t i = lo; i < hi; i++) b.extend(boundsOf(cells[ids[i]]));
+    const Box4 tight = b;            // ALLOW_EMPTY_CELLS: a leaf's bounds are rebuilt from its cells (:483-495)
     const int cw = 1 << (b.hi[3] - 1);
     for (int d = 0; d < 3; d++) { b.lo[d] = cw * divDown(b.lo[d], cw); b.hi[d] = cw * divUp(b.hi[d], cw); }
     const size_t n = hi - lo;
     // tryMakeLeaf (:447-530)
     if (b.size(3) <= 1 && b.size(0) / cw <= maxLeafWidth && b.size(1) / cw <= maxLeafWidth && b.size(2) / cw <= maxLeafWidth
-        && uint64_t(int64_t(b.size(0))) * uint64_t(int64_t(b.size(1))) * uint64_t(int64_t(b.size(2))) * uint64_t(int64_t(b.size(3)))
-               == uint64_t(n) * uint64_t(cw) * cw * cw) {
-      emitBrick(b, lo, hi);
+        && (allowEmptyCells        // ALLOW_EMPTY_CELLS: partially filled bricks pass, their holes keep the id -1 (:473-495)
+            || uint64_t(int64_t(b.size(0))) * uint64_t(int64_t(b.size(1))) * uint64_t(int64_t(b.size(2))) * uint64_t(int64_t(b.size(3)))
+                   == uint64_t(n) * uint64_t(cw) * cw * cw)) {
+      emitBrick(allowEmptyCells ? tight : b, lo, hi);
       return;
     }
     const int dims[3] = { b.size(0) / cw, b.size(1) / cw, b.size(2) / cw };
@@ -192,7 +195,7 @@ struct Builder {
 int main(int argc, char **argv)
 {
   try {
-    bool spatialMedian = false, largeBricks = false, verbose = false;
+    bool spatialMedian = false, largeBricks = false, verbose = false, allowEmptyCells = false;
     int maxLeafWidth = 127;
     std::string in, out;
     for (int i = 1; i < argc; i++) {
@@ -203,6 +206,7 @@ int main(int argc, char **argv)
       else if (a == "--parallel") {}
       else if (a == "--max-leaf-width" && i + 1 < argc) maxLeafWidth = std::stoi(argv[++i]);
       else if (a == "-v") verbose = true;
+      else if (a == "--allow-empty-cells") allowEmptyCells = true;
       else if (a == "--no-shift-planes" || a == "--no-planes" || a == "--spatial-median" || a == "--spatial-median-builder") spatialMedian = true;
       else if (a == "--large-bricks") largeBricks = true;
       else throw std::runtime_error("un-recognized cmdline arg '" + a + "'");
@@ -220,6 +224,7 @@ int main(int argc, char **argv)
     for (const Cell &c : cells) if (c.level < 0 || c.level > 30) throw std::runtime_error("cell level out of range");
     const int type = (!spatialMedian && !largeBricks) ? SAH_ALIKE : (largeBricks ? SMALL_BRICK_COUNT : SPATIAL_MEDIAN);
     Builder b(cells, type, maxLeafWidth, verbose);
+    b.allowEmptyCells = allowEmptyCells;
     b.initialIds();
     if (b.ids.empty()) throw std::runtime_error("no cells");
     b.build(0, b.ids.size());

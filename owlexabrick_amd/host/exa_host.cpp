@@ -329,8 +329,9 @@ void Renderer::init(std::vector<TriangleMesh::SP> surfaces, const std::vector<in
   std::vector<uint64_t> len;
   for (auto &f : fields) { ptr.push_back(f->value.data()); len.push_back(f->value.size()); }
   const int nRegionFields = multiFieldDvr ? (int)fields.size() : 1;                  // OptixRenderer.cpp:154
-  if (exa_prep_create(in->bricks7.data(), in->numBricks(), in->cellIDs.data(), in->cellIDs.size(),
-                      ptr.data(), len.data(), (int)fields.size(), nRegionFields, 0, &prep))
+  if (exa_prep_create_ex(in->bricks7.data(), in->numBricks(), in->cellIDs.data(), in->cellIDs.size(),
+                         ptr.data(), len.data(), (int)fields.size(), nRegionFields, 0,
+                         in->allowEmptyCells ? EXA_PREP_ALLOW_EMPTY_CELLS : 0, &prep))
     throw std::runtime_error(exa_prep_last_error());
   ExaHipScene scene;
   exa_prep_scene(prep, &scene);

@@ -90,6 +90,9 @@ struct ExaBricks {
   std::vector<int32_t> bricks7;
   std::vector<int32_t> cellIDs;      // concatenated per-brick cell ids
   size_t totalNumCells = 0;
+  // the reference's build option ALLOW_EMPTY_CELLS (CMakeLists.txt:70-73), here a property of the loaded bricks: cell id -1
+  // = no cell (exa/ExaBricks.cpp:46-49); the renderer then gathers the poison value for it and skips such corners
+  bool allowEmptyCells = false;
   size_t numBricks() const { return bricks7.size() / 7; }
   static SP load(const std::string &brickFileName);        // exa/ExaBricks.cpp:21-55
   void save(const std::string &brickFileName) const;       // builder/builder.cpp:895-902

@@ -31,6 +31,25 @@ class Scene:
         return lo.astype(np.float32), hi.astype(np.float32)
 
 
+def with_empty_cells(scene, fraction=0.1, seed=0, whole_rows=True):
+    """the same scene with some cells missing: their ids become -1, what the reference admits when it is built with
+    -DALLOW_EMPTY_CELLS=1 (exa/ExaBricks.cpp:46-49; exaBuilder writes -1 for the holes of a partially filled brick,
+    builder/builder.cpp:473-495).  Deterministic in (scene, fraction, seed); whole_rows also knocks out a few complete
+    x-rows, so that samples with four and more empty corners occur."""
+    rng = np.random.default_rng(0xE3B7 + seed)
+    ids = np.array(scene.cellIDs, dtype=np.int32, copy=True)
+    ids[rng.uniform(size=ids.size) < fraction] = -1
+    if whole_rows:
+        begin = 0
+        for r in np.asarray(scene.bricks7).reshape(-1, 7):
+            sx, sy, sz = int(r[0]), int(r[1]), int(r[2])
+            if rng.uniform() < 0.3 and sy > 1:
+                y, z = int(rng.integers(sy)), int(rng.integers(sz))
+                ids[begin + (z * sy + y) * sx: begin + (z * sy + y) * sx + sx] = -1
+            begin += sx * sy * sz
+    return Scene(scene.bricks7, ids, scene.fields, name=scene.name + "_holes", value_range=scene.value_range, meta=dict(scene.meta))
+
+
 def parse_grids(text):
     """tools/artificial/artificial.cpp:140-171: 15-value or 8-value lines; others ignored."""
     grids = []

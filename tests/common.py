@@ -31,7 +31,7 @@ class Case:
     def __init__(self, scene, W=64, H=64, grad=0, iso=None, xf=None, dt=0.5, opacity_scale=1.0,
                  space_skipping=1, ao=0, ao_length=1e20, clip=None, frameID=0, camera=None,
                  xfm=None, grad_iso=1, multi=True, xf_domains=None, accel=None, fast_math=None, contour=None, meshes=None,
-                 tf_filter=None, basis_form=None):
+                 tf_filter=None, basis_form=None, allow_empty_cells=False):
         self.scene, self.W, self.H = scene, W, H
         # association of the eight-corner basis sums on BOTH sides (oracle: or_set_basis_form, module: option basis_form):
         # 0 = the reference's source order, 1 = per axis with fused multiply-adds; None = the module's default, which the
@@ -41,6 +41,9 @@ class Case:
         from owlexabrick_amd.binding import DEFAULT_BASIS_FORM
         self.basis_form = basis_form if basis_form is not None else (int(env) if env else DEFAULT_BASIS_FORM)
         self.grad, self.iso, self.dt = grad, iso, dt
+        self.allow_empty_cells = allow_empty_cells     # the reference's build option ALLOW_EMPTY_CELLS: cell id -1 = no cell
+        if allow_empty_cells:
+            self.basis_form = 0                        # an empty cell is a per-corner property: source order only
         self.xfs = xf if isinstance(xf, list) else [xf if xf is not None else ramp_xf()] * len(scene.fields)
         self.opacity_scale, self.space_skipping = opacity_scale, space_skipping
         self.ao, self.ao_length, self.clip, self.frameID = ao, ao_length, clip, frameID
@@ -72,7 +75,8 @@ class Case:
     # ---- oracle ----
     def oracle_scene(self):
         S = po.OracleScene(self.scene.bricks7, self.scene.cellIDs, self.scene.fields,
-                           num_region_fields=len(self.scene.fields) if self.multi else 1)
+                           num_region_fields=len(self.scene.fields) if self.multi else 1,
+                           allow_empty_cells=self.allow_empty_cells)
         for c, xf in enumerate(self.xfs):
             S.set_xf(c, xf)
         if self.tf_filter is not None:
@@ -115,7 +119,8 @@ class Case:
     # ---- HIP module through the C ABI ----
     def hip_renderer(self, device=0):
         from owlexabrick_amd import binding
-        prep = binding.Prep(self.scene, num_region_fields=len(self.scene.fields) if self.multi else 1)
+        prep = binding.Prep(self.scene, num_region_fields=len(self.scene.fields) if self.multi else 1,
+                            allow_empty_cells=self.allow_empty_cells)
         R = binding.Renderer(prep, device=device, multiFieldDvr=self.multi)
         if self.meshes:
             R.setTriangles(*self._merged_meshes())

@@ -1,5 +1,5 @@
 """Sweep of seeded random parity cases on a GPU box (not collected by pytest):
-    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids | --many | --deep | --domains] [--clip] [--keep-going]
+    python tests/gpu_fuzz.py FIRST LAST [--rich | --grids | --many | --deep | --domains] [--clip] [--holes] [--keep-going]
 For each seed: the oracle against the HIP module through the C ABI, both walks (kd, LBVH), library powf
 (`fast_math = 0`): accumulation buffer within the tolerance of tests/common.py, RGBA8 within 1 LSB, identical work
 counters, no slab-test mismatch; and the shipped kernel (counting off, `fast_math` 0 and 1 defaults) equal to the counting
@@ -16,7 +16,7 @@ from fuzz_cases import random_case, random_deep_case, random_rich_case
 STAT_KEYS = ["segments", "sample_evals", "samples", "brick_visits", "corner_loads", "iso_segments", "iso_evals"]
 
 
-def check(seed, rich=False, clipbox=False):
+def check(seed, rich=False, clipbox=False, holes=False):
     """list of failure strings (empty = pass)"""
     bad = []
     frames = 1
@@ -43,6 +43,15 @@ def check(seed, rich=False, clipbox=False):
         case.xf_domains = [[(0.0, 0.0), (0.5, 0.5), (1.0, 0.0), (0.4, 0.4001), (-5.0, 5.0), (0.9, 3.0), (-2.0, 0.1), (0.0, 1e-30),
                             (0.25, 0.75)][int(rng.integers(0, 9))] for _ in case.scene.fields]
         desc["xf_domains"] = case.xf_domains
+    if holes:
+        # the eighth family: any of the above with cells missing (ids -1), on a scene marked allowEmptyCells — the reference's
+        # ALLOW_EMPTY_CELLS build: poison value in the scalar buffers and the value ranges, corners skipped by the sampler
+        from owlexabrick_amd import scenes
+        rng = np.random.default_rng(0xE3F7000 + seed)
+        frac = float(rng.choice([0.02, 0.1, 0.3, 0.6]))
+        case.scene = scenes.with_empty_cells(case.scene, fraction=frac, seed=seed)
+        case.allow_empty_cells, case.basis_form = True, 0
+        desc["empty_fraction"] = frac
     case.fast_math = 0
     o = case.run_oracle(frames=frames)
     for accel in (1, 0):
@@ -97,7 +106,7 @@ if __name__ == "__main__":
     rich = True if "--rich" in sys.argv else ("grids" if "--grids" in sys.argv else ("many" if "--many" in sys.argv else ("deep" if "--deep" in sys.argv else ("domains" if "--domains" in sys.argv else False))))
     fails, t0 = 0, time.time()
     for seed in range(first, last + 1):
-        bad, desc = check(seed, rich, clipbox=("--clip" in sys.argv))
+        bad, desc = check(seed, rich, clipbox=("--clip" in sys.argv), holes=("--holes" in sys.argv))
         if bad:
             fails += 1
             print(f"FAIL seed {seed}: {desc}", flush=True)

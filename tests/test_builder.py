@@ -9,7 +9,7 @@ import pytest
 
 from common import ROOT
 from oracle import builder_oracle as bo
-from owlexabrick_amd import scenes
+from owlexabrick_amd import binding, scenes
 
 EXE = os.path.join(ROOT, "owlexabrick_amd", "host", "exaBuilder")
 FLAGS = {bo.SAH_ALIKE: [], bo.SPATIAL_MEDIAN: ["--spatial-median"], bo.SMALL_BRICK_COUNT: ["--large-bricks"]}
@@ -154,3 +154,40 @@ def test_generated_scene_on_builder_made_bricks_holds_the_same_cells():
     ka, va = keyed(sc)
     kb, vb = keyed(sb)
     assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+
+
+@pytest.mark.parametrize("btype", [bo.SAH_ALIKE, bo.SPATIAL_MEDIAN, bo.SMALL_BRICK_COUNT])
+@pytest.mark.parametrize("seed", range(4))
+def test_builder_allows_partially_filled_bricks_with_empty_cells(seed, btype):
+    """--allow-empty-cells = the reference built with -DALLOW_EMPTY_CELLS=1 (builder/builder.cpp:473-495): a single-level
+    set that fits a leaf becomes one even when cells are missing; the holes keep the id -1.  Byte for byte the restatement,
+    every input cell in exactly one brick slot, and the result loads with the renderer's empty-cells option."""
+    rng = np.random.default_rng(0xB11D + seed)
+    full = cells_of(scenes.amr(seed=3 + seed, root=(2, 2, 1), B=4, levels=2))
+    cells = full[rng.uniform(size=len(full)) > 0.25]                       # a quarter of the cells missing
+    r, data = run_builder(cells, FLAGS[btype] + ["--allow-empty-cells"], max_leaf_width=6)
+    assert r.returncode == 0, r.stderr
+    assert data == bo.to_bricks_file_bytes(bo.build_bricks(cells, btype, max_leaf_width=6, allow_empty_cells=True))
+    # parse the .bricks stream: ids are a permutation of the input cells plus -1 holes
+    a = np.frombuffer(data, dtype=np.int32)
+    at, ids, b7 = 0, [], []
+    while at < len(a):
+        sx, sy, sz = a[at:at + 3]
+        b7.append(a[at:at + 7])
+        ids.append(a[at + 7:at + 7 + sx * sy * sz])
+        at += 7 + sx * sy * sz
+    ids = np.concatenate(ids)
+    assert (ids == -1).sum() > 0 and sorted(ids[ids >= 0].tolist()) == list(range(len(cells)))
+    # without the option the same cells need far more (fully filled) bricks
+    r2, data2 = run_builder(cells, FLAGS[btype], max_leaf_width=6)
+    assert r2.returncode == 0 and len(np.frombuffer(data2, dtype=np.int32)) > 0
+    n2 = 0
+    a2, at = np.frombuffer(data2, dtype=np.int32), 0
+    while at < len(a2):
+        at += 7 + int(a2[at]) * int(a2[at + 1]) * int(a2[at + 2]); n2 += 1
+    assert n2 > len(b7)
+    # the host preparation takes the holes with its empty-cells flag
+    sc = scenes.Scene(np.array(b7, dtype=np.int32), ids.astype(np.int32), [rng.uniform(size=len(cells)).astype(np.float32)])
+    P = binding.Prep(sc, allow_empty_cells=True)
+    assert (P.scalars() == np.float32(-1e20)).sum() == (ids == -1).sum()
+    P.close()
