@@ -290,8 +290,10 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * 2 / 4 = every tile with that many lanes (tests); "prepass_split" 1 (default) = in a frame with surfaces the tiles whose iso marches are
  * long (measured by the same frame that measures the tile costs) get their own pre-pass + march pipeline on a side stream,
  * beside the pre-pass + march of the other tiles (the pre-pass is bound by the latency of its longest rays, the march by
- * throughput), 0 = the whole pre-pass in front of the whole march; "ao_defer" 1 = the ambient-occlusion rays of the shaded hits are traced by a launch of their own,
- * one ray per lane over a compact list of the hits, 0 (default) = inline behind each pixel's primary ray; "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
+ * throughput), 0 = the whole pre-pass in front of the whole march; "ao_defer" 1 (default) = the ambient-occlusion rays of the shaded hits are traced by a launch of their own,
+ * one ray per lane over a compact list of the hits, 2 = as 1 with the listed rays sorted on the device by (32x32-pixel block of the
+ * hit | direction class: octant x dominant axis) before they are traced, so that a wave's 64 rays start close together and head
+ * the same way (counting sort: histogram, scan, scatter; hit flags combined per hit by a last kernel), 0 = inline behind each pixel's primary ray (1 is the default); "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
  * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change; "walk_probe" 1 = the
  * counting variant also records every wave's SET of visited kd nodes (128 KiB of device memory per wave) and reports its
  * size summed over the waves as walk_union_nodes (a diagnostic of how coherent the 64 walks of a wave are);

@@ -43,6 +43,9 @@
                                 // C3 is bound by the latency of its longest rays there (3 / 4 / 5 waves: 21.08 / 21.07 / 21.62 ms per frame),
                                 // C5 by throughput (3 waves + the march header kept in registers across a one-brick segment: 13.9 instead of 10.9 ms)
 #endif
+#ifndef EXA_AO_ISO_WAVES
+#define EXA_AO_ISO_WAVES 6      // waves per SIMD of the deferred AO rays' kernel (iso-only frames): the rays are latency-bound marches
+#endif
 #ifndef EXA_OPT_SORG
 #define EXA_OPT_SORG 1        // march: the (wave-uniform) ray origin in scalar registers (three VGPRs less to keep alive; time within noise)
 #endif
@@ -216,6 +219,12 @@ struct RenderArgs {
   uint32_t          *walkProbe;     // != null (counting variant, option walk_probe): per wave a hash set of kWalkProbeSize node ids
   AoRecord          *aoRecs;        // surfaces pre-pass -> AO kernel: one record per shaded hit (NULL: AO rays traced inline)
   uint32_t          *aoCount;       // surfaces pre-pass -> AO kernel: number of listed hits (cleared before the pre-pass)
+  // option ao_defer = 2: the listed rays sorted by (pixel block of the hit | direction class) before they are traced
+  uint32_t          *aoKeys;        // per ray (2 per hit): its bin (NULL: rays traced in list order)
+  uint32_t          *aoHist;        // per bin: count, then (scanned) the bin's cursor into aoOrder
+  uint32_t          *aoOrder;       // ray indices in bin order
+  uint8_t           *aoHit;         // per ray: hit flag
+  uint32_t           aoBins;
   uint32_t          *tileCostPre;   // != null: per tile id, steps of the longest iso march of the surfaces pre-pass
   uint32_t          *tileCost;      // != null: per tile id, brick visits of the tile's longest ray (launch-order feedback)
 };

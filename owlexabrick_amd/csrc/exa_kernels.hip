@@ -1912,12 +1912,111 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_PREPASS_ISO_WAVES : EXA_P
   }
 }
 
+// AO ray j of the deferred list: sample j & 1 of hit j >> 1 — the cosine-distributed direction from the hit's own LCG draws
+// (exabrick.cu:85-94, 1624-1633).  One definition for the tracing kernel and for the kernel that sorts the rays.
+__device__ __forceinline__ Ray aoRayOf(const ExaHipFrameState &fs, const float4 posFd, const float4 ngAmb, const float4 baseRnd, unsigned j)
+{
+  Lcg rnd;
+  rnd.state = __float_as_uint(baseRnd.w);
+  if (j & 1u) { rnd.next(); rnd.next(); }                       // the second sample's draws follow the first's
+  const V3 wN = mk(ngAmb.x, ngAmb.y, ngAmb.z);
+  const V3 vN = fabsf(wN.x) > fabsf(wN.y) ? normalize(mk(-wN.z, 0.f, wN.x)) : normalize(mk(0.f, wN.z, -wN.y));
+  const V3 uN = cross(vN, wN);
+  const float u1 = rnd.next(), u2 = rnd.next();
+  const float rr = sqrtf(u1);
+  const float theta = 2.f * 3.14159265358979323846f * u2;
+  const V3 sp = mk(rr * cosf(theta), rr * sinf(theta), sqrtf(1.f - u1));
+  Ray ao_ray;
+  ao_ray.org = mk(posFd.x, posFd.y, posFd.z);
+  ao_ray.dir = normalize((sp.x * uN + sp.y * vN) + sp.z * wN);
+  ao_ray.tmin = 1e-4f; ao_ray.tmax = fs.ao.length;
+  return ao_ray;
+}
+
+// ---- sorting the deferred AO rays (option ao_defer = 2) ----
+// The hits are listed in launch order of the pre-pass, two rays per hit in random directions of the hit's hemisphere: the 64
+// rays of a wave start close together and fly apart.  A counting sort by (32x32-pixel block of the hit | direction class)
+// puts rays that start close together AND head the same way into the same waves: key kernel (histogram) -> scan -> scatter
+// of the ray indices; the tracing kernel then takes its chunks from the sorted index list and writes one hit flag per ray,
+// and a last kernel combines the two flags of a hit.  Which lane traces a ray does not change the ray: same pixels.
+enum { kAoDirClasses = 24, kAoCellShift = 5 };
+__device__ __forceinline__ uint32_t aoRayKey(const RenderArgs &a, uint32_t slot, V3 d)
+{
+  // direction class: octant (3 sign bits) x dominant axis
+  const float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+  const uint32_t dom = (ax >= ay && ax >= az) ? 0u : (ay >= az ? 1u : 2u);
+  const uint32_t oct = (d.x < 0.f ? 1u : 0u) | (d.y < 0.f ? 2u : 0u) | (d.z < 0.f ? 4u : 0u);
+  // where the hit's pixel lies: 32x32-pixel blocks of the frame (one GPU), or groups of four of this rank's tiles
+  uint32_t cell;
+  if (a.world == 1) {
+    const uint32_t px = slot % (uint32_t)a.W, py = slot / (uint32_t)a.W;
+    cell = (py >> kAoCellShift) * (((uint32_t)a.W + 31u) >> kAoCellShift) + (px >> kAoCellShift);
+  } else {
+    cell = slot >> 10;
+  }
+  return cell * kAoDirClasses + oct * 3u + dom;
+}
+__global__ __launch_bounds__(256) void aoKeyKernel(const RenderArgs a)
+{
+  const unsigned numRays = 2u * a.aoCount[0];
+  for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < numRays; j += gridDim.x * 256u) {
+    const AoRecord *r = a.aoRecs + (j >> 1);
+    const Ray ray = aoRayOf(a.fs, r->posFd, r->ngAmb, r->baseRnd, j);
+    const uint32_t key = min(aoRayKey(a, r->slot, ray.dir), a.aoBins - 1u);
+    a.aoKeys[j] = key;
+    atomicAdd(&a.aoHist[key], 1u);
+  }
+}
+// exclusive prefix sum of the histogram, in place: one workgroup, each thread a contiguous run of bins
+__global__ __launch_bounds__(1024) void aoScanKernel(uint32_t *hist, uint32_t numBins)
+{
+  __shared__ uint32_t part[1024];
+  const uint32_t per = (numBins + 1023u) / 1024u;
+  const uint32_t b0 = min(threadIdx.x * per, numBins), b1 = min(b0 + per, numBins);
+  uint32_t sum = 0;
+  for (uint32_t b = b0; b < b1; b++) sum += hist[b];
+  part[threadIdx.x] = sum;
+  __syncthreads();
+  for (uint32_t off = 1; off < 1024u; off <<= 1) {
+    const uint32_t v = threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - sum;                      // exclusive prefix of this thread's run
+  for (uint32_t b = b0; b < b1; b++) { const uint32_t c = hist[b]; hist[b] = run; run += c; }
+}
+__global__ __launch_bounds__(256) void aoScatterKernel(const RenderArgs a)
+{
+  const unsigned numRays = 2u * a.aoCount[0];
+  for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < numRays; j += gridDim.x * 256u)
+    a.aoOrder[atomicAdd(&a.aoHist[a.aoKeys[j]], 1u)] = j;       // the scanned histogram doubles as the bins' cursors
+}
+// shadow term and background colour of every listed hit from its two rays' flags (exabrick.cu:1647-1650)
+__global__ __launch_bounds__(256) void aoFinalizeKernel(const RenderArgs a)
+{
+  const unsigned numHits = a.aoCount[0];
+  for (unsigned h = blockIdx.x * 256u + threadIdx.x; h < numHits; h += gridDim.x * 256u) {
+    const AoRecord *r = a.aoRecs + h;
+    const float4 posFd = r->posFd, ngAmb = r->ngAmb, baseRnd = r->baseRnd;
+    const uint32_t slot = r->slot;
+    const int hitCnt = (int)a.aoHit[2u * h] + (int)a.aoHit[2u * h + 1u];
+    const float shadow = (float)hitCnt / 2;                         // AO_Samples = 2 (:1613)
+    const float fd = posFd.w;
+    const float ns = 1.f - shadow;
+    const float t_hit = a.surf[slot].w;
+    a.surf[slot] = make_float4(ngAmb.w + baseRnd.x * fd * ns, ngAmb.w + baseRnd.y * fd * ns, ngAmb.w + baseRnd.z * fd * ns, t_hit);
+  }
+}
+
 // The ambient-occlusion rays of the hits surfacePrepassKdKernel<.., AO_DEFER> listed (exabrick.cu:1611-1652): lane 2h + i
 // traces sample i of hit h — the cosine-distributed direction from the hit's own LCG draws (:85-94, :1624-1633), the trace
 // through the surfaces without contour planes (:1638), hit or no hit — and the two lanes of a hit combine into the shadow
 // term and the hit's background colour (:1647-1650), which replaces the placeholder in a.surf.
-template <bool ISO_ONLY>
-__global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? 5 : EXA_PREPASS_WAVES)) void aoRaysKdKernel(const RenderArgs a)
+// SORTED: the chunks come from the sorted index list a.aoOrder and every ray writes its flag to a.aoHit (aoFinalizeKernel
+// combines them); otherwise lanes 2h, 2h + 1 hold the two rays of hit h and combine them with one shuffle.
+template <bool ISO_ONLY, bool SORTED>
+__global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_AO_ISO_WAVES : EXA_PREPASS_WAVES)) void aoRaysKdKernel(const RenderArgs a)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
@@ -1944,33 +2043,23 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? 5 : EXA_PREPASS_WAVES)) void 
     if ((threadIdx.x & 63) == 0) base = atomicAdd(&a.aoCount[2], 64u);
     base = (unsigned)__shfl((int)base, 0, 64);
     if (base >= numRays) break;
-    const unsigned j = base + (threadIdx.x & 63);
-    const bool live = j < numRays;
+    const unsigned k = base + (threadIdx.x & 63);
+    const bool live = k < numRays;
+    const unsigned j = (SORTED && live) ? a.aoOrder[k] : k;
     int hitFlag = 0;
     float4 posFd = make_float4(0.f, 0.f, 0.f, 0.f), ngAmb = posFd, baseRnd = posFd;
     uint32_t slot = 0;
     if (live) {
       const AoRecord *r = a.aoRecs + (j >> 1);
       posFd = r->posFd; ngAmb = r->ngAmb; baseRnd = r->baseRnd; slot = r->slot;
-      Lcg rnd;
-      rnd.state = __float_as_uint(baseRnd.w);
-      if (j & 1u) { rnd.next(); rnd.next(); }                       // the second sample's draws follow the first's
-      const V3 wN = mk(ngAmb.x, ngAmb.y, ngAmb.z);
-      const V3 vN = fabsf(wN.x) > fabsf(wN.y) ? normalize(mk(-wN.z, 0.f, wN.x)) : normalize(mk(0.f, wN.z, -wN.y));
-      const V3 uN = cross(vN, wN);
-      const float u1 = rnd.next(), u2 = rnd.next();
-      const float rr = sqrtf(u1);
-      const float theta = 2.f * 3.14159265358979323846f * u2;
-      const V3 sp = mk(rr * cosf(theta), rr * sinf(theta), sqrtf(1.f - u1));
-      Ray ao_ray;
-      ao_ray.org = mk(posFd.x, posFd.y, posFd.z);
-      ao_ray.dir = normalize((sp.x * uN + sp.y * vN) + sp.z * wN);
-      ao_ray.tmin = 1e-4f; ao_ray.tmax = fs.ao.length;
+      const Ray ao_ray = aoRayOf(fs, posFd, ngAmb, baseRnd, j);
       SurfaceHit ao;
       traceSurfacesKd<0, ISO_ONLY>(C, ao_ray, ao, false, stackF, qRegion, qT);
       if (ao.primID >= 0 || ao.primID == EXA_PRIMID_ISOSURFACE || ao.primID == EXA_PRIMID_PLANE
           || ao.primID == EXA_PRIMID_STREAMLINE) hitFlag = 1;
+      if (SORTED) a.aoHit[j] = (uint8_t)hitFlag;
     }
+    if (SORTED) continue;
     const int other = __shfl_xor(hitFlag, 1, 64);                    // the hit's other sample: the neighbouring lane
     if (live && !(j & 1u)) {
       const int hitCnt = hitFlag + other;
@@ -2727,11 +2816,23 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
   else              { if (defer) hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, true>), grid, block, lds, s, a);
                       else       hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, false>), grid, block, lds, s, a); }
   if (defer && a.fs.ao.enabled) {
-    const int maxBlocks = 256 * 5;                                   // what the device holds at once (5 workgroups per CU)
+    const int maxBlocks = 256 * (isoOnly ? EXA_AO_ISO_WAVES : EXA_PREPASS_WAVES);      // what the device holds at once (workgroups per CU = waves per SIMD)
     const long long upper = ((long long)numBlocks * kTilePixels * 2 + kKdBlock - 1) / kKdBlock;
     const dim3 g2((unsigned)(upper < maxBlocks ? upper : maxBlocks));
-    if (isoOnly) hipLaunchKernelGGL((aoRaysKdKernel<true>), g2, block, lds, s, a);
-    else         hipLaunchKernelGGL((aoRaysKdKernel<false>), g2, block, lds, s, a);
+    if (a.aoKeys) {
+      // sorted: histogram of the rays' bins -> scan -> scatter of the ray indices -> trace in that order -> combine per hit
+      const dim3 gs((unsigned)(upper < 2048 ? upper : 2048)), b256(256);
+      (void)hipMemsetAsync(a.aoHist, 0, size_t(a.aoBins) * sizeof(uint32_t), s);
+      hipLaunchKernelGGL(aoKeyKernel, gs, b256, 0, s, a);
+      hipLaunchKernelGGL(aoScanKernel, dim3(1), dim3(1024), 0, s, a.aoHist, a.aoBins);
+      hipLaunchKernelGGL(aoScatterKernel, gs, b256, 0, s, a);
+      if (isoOnly) hipLaunchKernelGGL((aoRaysKdKernel<true, true>), g2, block, lds, s, a);
+      else         hipLaunchKernelGGL((aoRaysKdKernel<false, true>), g2, block, lds, s, a);
+      hipLaunchKernelGGL(aoFinalizeKernel, gs, b256, 0, s, a);
+    } else {
+      if (isoOnly) hipLaunchKernelGGL((aoRaysKdKernel<true, false>), g2, block, lds, s, a);
+      else         hipLaunchKernelGGL((aoRaysKdKernel<false, false>), g2, block, lds, s, a);
+    }
   }
   return hipGetLastError();
 }

@@ -341,7 +341,10 @@ struct ExaHipRenderer {
   DevBuf<uint32_t> surfRnd;
   DevBuf<AoRecord> aoRecs;              // deferred AO rays: one record per shaded hit and pixel slot at most
   DevBuf<uint32_t> aoCount;             // [0..3] the frame's list (or the cheap pipeline's), [4..7] the heavy pipeline's
-  int aoDefer = 0;                      // option ao_defer (measured: C5 1462 vs 1478 ms per frame with it, C3 + AO 20.4 vs 19.4 ms)
+  DevBuf<uint32_t> aoKeys, aoOrder, aoHist;   // ao_defer = 2: bin of every listed ray, ray indices in bin order, 2 x aoBins counters (one set per pipeline)
+  DevBuf<uint8_t> aoHit;                // ... and the rays' hit flags
+  uint32_t aoBins = 0;
+  int aoDefer = 1;                      // option ao_defer: 1 (default since round 4: C5 1317 vs 1329 ms per 16-sample frame, C3 + iso + AO 15.8 vs 16.4 ms), 0 inline, 2 sorted
   DevBuf<uint32_t> color;
   DevBuf<int32_t> tileMap;
   int numBlocks = 0;
@@ -893,7 +896,7 @@ struct ExaHipRenderer {
       HIP_TRY(this, surfRnd.alloc(accum.n));
       a.surf = surf.p; a.surfRnd = surfRnd.p;
     }
-    a.aoRecs = nullptr; a.aoCount = nullptr;
+    a.aoRecs = nullptr; a.aoCount = nullptr; a.aoKeys = nullptr; a.aoHist = nullptr; a.aoOrder = nullptr; a.aoHit = nullptr; a.aoBins = 0;
     if (useKd() && surfacesEnabled() && fs.ao.enabled && aoDefer && !stats) {
       // one record per pixel of every launched tile, the padding pixels of partial edge tiles included: the heavy
       // pipeline's list starts behind nPreCheap WHOLE tiles (accum.n = W * H on one GPU is smaller when W or H is not a
@@ -903,6 +906,15 @@ struct ExaHipRenderer {
       if (!aoCount.p) HIP_TRY(this, aoCount.alloc(8));        // per pipeline: [0] listed hits, [2] the AO kernel's chunk counter
       HIP_TRY(this, hipMemsetAsync(aoCount.p, 0, 8 * sizeof(uint32_t), s));
       a.aoRecs = aoRecs.p; a.aoCount = aoCount.p;
+      a.aoKeys = nullptr;
+      if (aoDefer == 2) {
+        // bins: (32x32-pixel blocks of the frame, or groups of four of this shard's tiles) x 24 direction classes
+        const uint32_t cells = world <= 1 ? uint32_t((W + 31) / 32) * uint32_t((H + 31) / 32) : uint32_t((numBlocks + 3) / 4);
+        const uint32_t bins = std::max(1u, cells) * 24u;
+        if (aoKeys.n != 2 * recs) { HIP_TRY(this, aoKeys.alloc(2 * recs)); HIP_TRY(this, aoOrder.alloc(2 * recs)); HIP_TRY(this, aoHit.alloc(2 * recs)); }
+        if (aoBins != bins) { HIP_TRY(this, aoHist.alloc(2 * size_t(bins))); aoBins = bins; }
+        a.aoKeys = aoKeys.p; a.aoOrder = aoOrder.p; a.aoHit = aoHit.p; a.aoHist = aoHist.p; a.aoBins = bins;
+      }
     }
     HIP_TRY(this, hipEventRecord(ev0, s));
     if (useKd()) {
@@ -919,6 +931,10 @@ struct ExaHipRenderer {
         if (a.aoRecs) {                                   // each pipeline appends to its own list
           ah.aoRecs = a.aoRecs + size_t(nPreCheap) * kTilePixels;
           ah.aoCount = a.aoCount + 4;
+          if (a.aoKeys) {
+            const size_t off = 2 * size_t(nPreCheap) * kTilePixels;
+            ah.aoKeys = a.aoKeys + off; ah.aoOrder = a.aoOrder + off; ah.aoHit = a.aoHit + off; ah.aoHist = a.aoHist + a.aoBins;
+          }
         }
         HIP_TRY(this, hipStreamWaitEvent(side2, evFork, 0));
         HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(ah, nPreHeavy, false, side2));
@@ -1557,7 +1573,10 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     if (value != 1 && value != 2) { h->fail("exa_hip_set_option: stats_mode is 1 or 2"); return 1; }
     h->statsMode = value; return 0;
   }
-  if (!std::strcmp(key, "ao_defer")) { h->aoDefer = value != 0; return 0; }
+  if (!std::strcmp(key, "ao_defer")) {
+    if (value < 0 || value > 2) { h->fail("exa_hip_set_option: ao_defer is 0, 1 or 2"); return 1; }
+    h->aoDefer = value; return 0;
+  }
   if (!std::strcmp(key, "prepass_split")) { h->prepassSplit = value != 0; h->costPhase = 1; return 0; }
   if (!std::strcmp(key, "walk_probe")) { h->walkProbeOn = value != 0; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }

@@ -112,9 +112,9 @@ def test_prepass_split_launch_plan_does_not_change_the_frame(size):
     sc = scenes.config("c3_gear", scale=0.2)
     kw = dict(W=size[0], H=size[1], grad=1, iso=[(0.5, 0)], ao=1, ao_length=200.0, xf_domains=[(0.0, 1.0)] * len(sc.fields))
     outs = {}
-    for split in (0, 1, 2):                      # 2: the split plan with the AO rays traced inline
+    for split in (0, 1, 2, 3):                   # 2: the split plan with the AO rays traced inline, 3: deferred and sorted
         case = Case(sc, **kw)
-        case.options = dict(prepass_split=min(split, 1), ao_defer=0 if split in (0, 2) else 1)
+        case.options = dict(prepass_split=min(split, 1), ao_defer={0: 0, 1: 1, 2: 0, 3: 2}[split])
         R = case.hip_renderer()
         frames = []
         for f in range(4):                       # frame 0 measures the costs, the later ones run the plan
@@ -122,7 +122,7 @@ def test_prepass_split_launch_plan_does_not_change_the_frame(size):
             frames.append(R.render().copy())
         outs[split] = (frames, R.readAccum().copy())
         R.close()
-    for k in (1, 2):
+    for k in (1, 2, 3):
         for f in range(4):
             assert np.array_equal(outs[0][0][f], outs[k][0][f]), (k, f)
         assert np.array_equal(outs[0][1].view(np.uint32), outs[k][1].view(np.uint32)), k
@@ -140,7 +140,7 @@ def test_deferred_ao_rays_equal_inline_ao_rays(world):
     for meshes in (None, [tri]):
         kw = dict(W=104, H=72, grad=1, iso=[(0.42, 0), (0.5, 1)], ao=1, ao_length=30.0, meshes=meshes)
         outs = []
-        for defer in (0, 1):
+        for defer in (0, 1, 2):
             case = Case(sc, **kw)
             case.options = dict(ao_defer=defer)
             R = case.hip_renderer()
@@ -150,5 +150,6 @@ def test_deferred_ao_rays_equal_inline_ao_rays(world):
                 img = R.render().copy()
             outs.append((img, R.readAccum().copy()))
             R.close()
-        assert np.array_equal(outs[0][0], outs[1][0])
-        assert np.array_equal(outs[0][1].view(np.uint32), outs[1][1].view(np.uint32))
+        for k in (1, 2):                                 # 2: the listed rays sorted by pixel block and direction class first
+            assert np.array_equal(outs[0][0], outs[k][0]), k
+            assert np.array_equal(outs[0][1].view(np.uint32), outs[k][1].view(np.uint32)), k
