@@ -18,6 +18,7 @@ if [ "$mode" = build ]; then
       d="$OUT/obj_$name"; mkdir -p "$d"
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -DEXA_BASIS_FORM=0 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f0.o" &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -DEXA_BASIS_FORM=1 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f1.o" &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -DEXA_BASIS_FORM=0 -DEXA_EMPTY_CELLS=1 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f0e.o" &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c "$CS/exa_lbvh.hip" -o "$d/exa_lbvh.o" &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -x hip -c "$CS/exa_module.cpp" -o "$d/exa_module.o" &&
       /opt/rocm/bin/hipcc $FLAGS -c "$CS/exa_prep.cpp" -o "$d/exa_prep.o" &&
