@@ -1,4 +1,4 @@
-"""The ORACLE against the definitions on seeded random brick partitions (CPU only):  python tests/fuzz_oracle.py FIRST LAST
+"""The ORACLE against the definitions on seeded random brick partitions (CPU only):  python tests/fuzz_oracle.py FIRST LAST [--per-axis]
 Random partitions into bricks of any shape and level with holes (tests/fuzz_cases._random_grids).  Three checks that do
 not share code with the oracle's march: (a) samplePoint[WithDerivative] == the hat-basis reconstruction summed over ALL
 cells of the overlapping bricks (test_oracle_kat._hat_reconstruction); (b) the regions are a disjoint partition of the
@@ -77,9 +77,10 @@ def check(seed, basis_form=0):
 
 if __name__ == "__main__":
     first, last = int(sys.argv[1]), int(sys.argv[2])
+    form = 1 if "--per-axis" in sys.argv else 0          # association of the basis sums (or_set_basis_form)
     fails, t0 = 0, time.time()
     for seed in range(first, last + 1):
-        bad, desc = check(seed)
+        bad, desc = check(seed, basis_form=form)
         if bad:
             fails += 1
             print(f"FAIL seed {seed}: {desc} {bad}", flush=True)
