@@ -816,11 +816,19 @@ __device__ __forceinline__ float firstSampleT(float t0, float dt, float off)
 {
   const int i0 = int(ceilf((t0 - dt * off) / dt));
   float t_i = (off + i0) * dt;
-  // the two correction loops almost never run: keep them rolled (unrolled 16x they were 400 instructions)
+  // the two correction loops almost never run: keep them rolled (unrolled 16x they were 400 instructions), and behind a
+  // test of their own — as a plain `for` the first one was compiled with ~15 scalar instructions of loop control that every
+  // pop executed (it is the same sequence of subtractions / additions either way)
+  if ((t_i - dt) >= t0) {
+    int g = 0;
 #pragma unroll 1
-  for (int g = 0; g < 64 && (t_i - dt) >= t0; g++) t_i = t_i - dt;
+    do { t_i = t_i - dt; } while (++g < 64 && (t_i - dt) >= t0);
+  }
+  if (t_i < t0) {
+    int g = 0;
 #pragma unroll 1
-  for (int g = 0; g < 64 && t_i < t0; g++) t_i += dt;
+    do { t_i += dt; } while (++g < 64 && t_i < t0);
+  }
   return t_i;
 }
 // the same with x / dt as x * invDt, for a step that is a power of two (invDt = 1/dt exactly, so quotient and product
@@ -829,10 +837,16 @@ __device__ __forceinline__ float firstSampleTPow2(float t0, float dt, float invD
 {
   const int i0 = int(ceilf((t0 - dt * off) * invDt));
   float t_i = (off + i0) * dt;
+  if ((t_i - dt) >= t0) {
+    int g = 0;
 #pragma unroll 1
-  for (int g = 0; g < 64 && (t_i - dt) >= t0; g++) t_i = t_i - dt;
+    do { t_i = t_i - dt; } while (++g < 64 && (t_i - dt) >= t0);
+  }
+  if (t_i < t0) {
+    int g = 0;
 #pragma unroll 1
-  for (int g = 0; g < 64 && t_i < t0; g++) t_i += dt;
+    do { t_i += dt; } while (++g < 64 && t_i < t0);
+  }
   return t_i;
 }
 
@@ -1491,6 +1505,17 @@ struct Packed {
   unsigned v;
   __device__ __forceinline__ int get(int sh) const { return (v >> sh) & 15; }
   __device__ __forceinline__ void set(int sh, int x) { v = (v & ~(15u << sh)) | ((unsigned)x << sh); }
+  // cheaper forms for the updates every pop / push / accept makes (same values as get + set):
+  __device__ __forceinline__ void inc(int sh) { v += 1u << sh; }                 // field + 1 (caller: no overflow of the 4 bits)
+  __device__ __forceinline__ void dec(int sh) { v -= 1u << sh; }                 // field - 1 (caller: field > 0)
+  __device__ __forceinline__ void setBit(int sh) { v |= 1u << sh; }              // a 0 / 1 field := 1
+  __device__ __forceinline__ void clearField(int sh) { v &= ~(15u << sh); }      // field := 0
+  // ring index + 1 modulo N (N a power of two: add and mask in place; else compare and select)
+  template <int N> __device__ __forceinline__ void incWrap(int sh)
+  {
+    if ((N & (N - 1)) == 0) v = (v & ~(15u << sh)) | ((v + (1u << sh)) & ((unsigned)(N - 1) << sh));
+    else { const int x = get(sh); set(sh, x == N - 1 ? 0 : x + 1); }
+  }
 };
 enum { PK_SHEAD = 0, PK_SCOUNT = 4, PK_DROPPED = 8, PK_QHEAD = 12, PK_QCOUNT = 16, PK_NEEDHDR = 20 };
 
@@ -1510,7 +1535,7 @@ __device__ __forceinline__ void kdPop(Ctx<STATS> &C, KdWalk &w, const int root, 
     int head = w.pk.get(PK_SHEAD);
     head = head == 0 ? KS - 1 : head - 1;
     w.pk.set(PK_SHEAD, head);
-    w.pk.set(PK_SCOUNT, count - 1);
+    w.pk.dec(PK_SCOUNT);
     w.ref = C.stack[head * kKdBlock];
     w.tn = stackF[(2 * head) * kKdBlock];
     w.tf = stackF[(2 * head + 1) * kKdBlock];
@@ -1571,7 +1596,7 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
       qRegion[slot * kKdBlock] = region;
       qT[(2 * slot) * kKdBlock] = t0;
       qT[(2 * slot + 1) * kKdBlock] = t1;
-      w.pk.set(PK_QCOUNT, qc + 1);
+      w.pk.inc(PK_QCOUNT);
       walkTmin = t1 * (1.0000001f);                          // exabrick.cu:1698 / :1457
       if (ISOWALK) walkTmax = walkTmax * dtScale;            // the next trace's tmax (:1434)
     }
@@ -1630,8 +1655,8 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
       C.stack[head * kKdBlock] = farRef;
       stackF[(2 * head) * kKdBlock] = ts;
       stackF[(2 * head + 1) * kKdBlock] = w.tf;
-      w.pk.set(PK_SHEAD, head == KS - 1 ? 0 : head + 1);
-      if (count == KS) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count + 1);
+      w.pk.template incWrap<KS>(PK_SHEAD);
+      if (count == KS) w.pk.setBit(PK_DROPPED); else w.pk.inc(PK_SCOUNT);
     }
     w.ref = nearRef;
     w.tf = ts;
@@ -1691,8 +1716,8 @@ __device__ SurfaceHit traceIsoRayKd(Ctx<STATS> &C, Ray ray, float off, float *st
     const int qh = w.pk.get(PK_QHEAD);
     const int region = qRegion[qh * kKdBlock];
     const float t0 = qT[(2 * qh) * kKdBlock], t1 = qT[(2 * qh + 1) * kKdBlock];
-    w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
-    w.pk.set(PK_QCOUNT, qc - 1);
+    w.pk.template incWrap<kSegQueue>(PK_QHEAD);
+    w.pk.dec(PK_QCOUNT);
     C.count(ST_ISO_SEGMENTS);
     const RegionInfo ri = a.sc.regionInfo[region];
     IsoResult ir;
@@ -2240,8 +2265,8 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         const int region = qRegion[qh * kKdBlock];
         const float t0 = qT[(2 * qh) * kKdBlock];
         t1 = qT[(2 * qh + 1) * kKdBlock];
-        w.pk.set(PK_QHEAD, qh == kSegQueue - 1 ? 0 : qh + 1);
-        w.pk.set(PK_QCOUNT, qc - 1);
+        w.pk.template incWrap<kSegQueue>(PK_QHEAD);
+        w.pk.dec(PK_QCOUNT);
         if (a.leafBeginBits) {
           // the leaf reference of the march tree is the region's record itself: no load between the queue and
           // the first brick record
@@ -2256,7 +2281,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         }
         C.count(ST_SEGMENTS);
         haveSeg = true;
-        w.pk.set(PK_NEEDHDR, 1);
+        w.pk.setBit(PK_NEEDHDR);
         if (EXA_OPT_DTPOW2 && a.invDtPow2 != 0.f)                                   // :1141-1144
           t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float(0x7f000000 - __float_as_int(flcw)), interleavedSamplingOffset);
         else
@@ -2285,7 +2310,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
           const unsigned at = 2u * (unsigned)(listBegin + child);
           hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
         }
-        w.pk.set(PK_NEEDHDR, 0);
+        w.pk.clearField(PK_NEEDHDR);
       }
       if (NCH) addBasisFastIl<GRAD, SMALL, (NCH ? NCH : 2)>(B, xWV, xD, hb0, hb1, a.cellsIl, ray.org + t_sample * ray.dir);
       else addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
@@ -2483,8 +2508,8 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
       C.stack[head * kKdBlock] = farRef;
       stackF[(2 * head) * kKdBlock] = ts;
       stackF[(2 * head + 1) * kKdBlock] = w.tf;
-      w.pk.set(PK_SHEAD, head == kKdStackEntries - 1 ? 0 : head + 1);
-      if (count_ == kKdStackEntries) w.pk.set(PK_DROPPED, 1); else w.pk.set(PK_SCOUNT, count_ + 1);
+      w.pk.template incWrap<kKdStackEntries>(PK_SHEAD);
+      if (count_ == kKdStackEntries) w.pk.setBit(PK_DROPPED); else w.pk.inc(PK_SCOUNT);
     }
     w.ref = nearRef;
     w.tf = ts;
