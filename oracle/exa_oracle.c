@@ -36,6 +36,8 @@ static inline v3 vscale(float s, v3 a) { return V3(s * a.x, s * a.y, s * a.z); }
 static inline v3 vneg(v3 a) { return V3(-a.x, -a.y, -a.z); }
 static inline float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 static inline float vlength(v3 a) { return sqrtf(vdot(a, a)); }
+/* the same sum, left to right, with both additions fused into their products (basis form 1) */
+static inline float vdotf(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
 /* owl normalize(v) = v * rsqrt(dot(v,v)); host rsqrt(f) = 1.f/sqrtf(f) */
 static inline v3 vnormalize(v3 a) { return vscale(1.f / sqrtf(vdot(a, a)), a); }
 static inline v3 vcross(v3 a, v3 b)
@@ -749,16 +751,22 @@ static void add_basis_functions(Ctx *C, Basis *B, int need_derivative, int brick
  *     weights:    sumW += (Sz*Sy)*Sx    sumDC.x += (Sz*Sy)*Mx    sumDC.y += (Sz*Sx)*My    sumDC.z += (Sy*Sx)*Mz
  * with S = wl + wh and M = ml + mh per axis.  Every `p*q + r` below is ONE fused multiply-add (fmaf), every other
  * operation one IEEE binary32 operation, in exactly this order; the HIP kernels execute the same sequence
- * (exa_kernels.hip: addBasisFactored).  49 operations per brick with derivatives where the source order takes 116. */
+ * (exa_kernels.hip: addBasisFast under EXA_BASIS_FORM == 1).  49 operations per brick with derivatives where the source
+ * order takes 116.  Form 1 also fuses the multiply-adds AROUND these sums, each at its site below: the cell coordinate
+ * (pos - lower) / cw - 0.5 here, the gradient sumW * sumD - sumWV * sumDC (sample_point_with_derivative), the DVR sample
+ * position org + t * dir (integrate_brick), the three dot products of the shading factor and the colour terms of the "over"
+ * operator (integrate_volume). */
 static void add_basis_functions_factored(Ctx *C, Basis *B, int need_derivative, int brickID, v3 pos, int channel)
 {
   const OrBrick *brick = &C->S->bricks[brickID];
   const float cellWidth = (float)(1 << brick->level);
   C->st.brick_visits++;
 
-  /* position in the brick, low cell index and fraction: as in the source order (:624-632) */
+  /* position in the brick (:624-632) with the division by the power-of-two cell width as an exact multiplication fused with
+   * the -0.5; low cell index and fraction as in the source order */
   const v3 lower = V3((float)brick->lower[0], (float)brick->lower[1], (float)brick->lower[2]);
-  const v3 localPos = vsub(vdiv(vsub(pos, lower), v3s(cellWidth)), v3s(0.5f));
+  const float invCw = 1.f / cellWidth;
+  const v3 localPos = V3(fmaf(pos.x - lower.x, invCw, -0.5f), fmaf(pos.y - lower.y, invCw, -0.5f), fmaf(pos.z - lower.z, invCw, -0.5f));
   int lx = f2i(floorf(localPos.x)), ly = f2i(floorf(localPos.y)), lz = f2i(floorf(localPos.z));
   lx = lx > -1 ? lx : -1; ly = ly > -1 ? ly : -1; lz = lz > -1 ? lz : -1;
   const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
@@ -840,6 +848,11 @@ static int sample_point_with_derivative(Ctx *C, float *value, v3 *derivatives, i
     add_basis(C, &B, 1, childList[childID], pos, channel);
   if (B.sumW <= 1e-20f) return 0;
   *value = B.sumWV / B.sumW;
+  if (C->S->basisForm)      /* form 1: the product-difference with its first product fused */
+    *derivatives = V3(fmaf(B.sumW, B.sumD.x, -(B.sumWV * B.sumDC.x)),
+                      fmaf(B.sumW, B.sumD.y, -(B.sumWV * B.sumDC.y)),
+                      fmaf(B.sumW, B.sumD.z, -(B.sumWV * B.sumDC.z)));
+  else
   *derivatives = V3(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
                     B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
                     B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);       /* :916-918 */
@@ -869,6 +882,23 @@ static void integrate_volume(Ctx *C, const Ray *ray, IntegrationResult *result, 
   if (actual_dt == 0.f) return;
   v4 *pixelColor = result->pixelColor;
   v4 sample = lookup_xf(C->S, C->fs, cellValue, channel);
+  if (C->S->basisForm) {
+    /* form 1: the same expressions with the additions of the three dot products and of the "over" operator's colour terms
+     * fused into their products (vdotf: left to right, like vdot) */
+    if (sqrtf(vdotf(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
+      const v3 lightDir = vneg(ray->dir);
+      const float scale = fabsf(vdotf(lightDir, gradient))
+                        / sqrtf(vdotf(gradient, gradient) * vdotf(lightDir, lightDir));
+      sample.x *= scale; sample.y *= scale; sample.z *= scale;
+    }
+    sample.w = 1.f - powf(1.f - sample.w, actual_dt);
+    const float k = (1.f - pixelColor->w) * sample.w;
+    pixelColor->x = fmaf(k, sample.x, pixelColor->x);
+    pixelColor->y = fmaf(k, sample.y, pixelColor->y);
+    pixelColor->z = fmaf(k, sample.z, pixelColor->z);
+    pixelColor->w += k * 1.f;
+    return;
+  }
   if (vlength(gradient) > finestLevelCellWidth * 1e-6f) {
     const v3 lightDir = vneg(ray->dir);
     const float scale = fabsf(vdot(lightDir, gradient))
@@ -971,7 +1001,10 @@ static void integrate_brick(Ctx *C, int gradient_shading, IntegrationResult *res
     const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
     const float actual_dt = t_next - t_last;
     t_last = t_next;
-    const v3 pos = vadd(ray->org, vscale(t_sample, ray->dir));
+    /* form 1: org + t * dir with the addition fused into the product (the DVR march only; the iso march keeps two roundings) */
+    const v3 pos = C->S->basisForm ? V3(fmaf(t_sample, ray->dir.x, ray->org.x), fmaf(t_sample, ray->dir.y, ray->org.y),
+                                        fmaf(t_sample, ray->dir.z, ray->org.z))
+                                   : vadd(ray->org, vscale(t_sample, ray->dir));
     float cellValue = 0.f;
     v3 grad = v3s(0.f);
     for (int c = 0; c < numChannels; ++c) {

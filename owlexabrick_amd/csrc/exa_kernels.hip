@@ -29,6 +29,10 @@
 #else
 #error "EXA_BASIS_FORM is 0 (source order) or 1 (per-axis association with fused multiply-adds)"
 #endif
+// form 1 also fuses the multiply-adds around the basis sums, each mirrored in the oracle (or_set_basis_form): the DVR sample
+// position org + t * dir, the cell coordinate (pos - lower) * 2^-level - 0.5, the gradient sumW * sumD - sumWV * sumDC, the
+// three dot products of the shading factor and the colour terms of the "over" operator
+#define EXA_F1 (EXA_BASIS_FORM == 1)
 namespace exa {
 namespace EXA_FORM_NS {
 
@@ -43,6 +47,17 @@ __device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y -
 __device__ __forceinline__ V3 operator*(float s, V3 a) { return mk(s * a.x, s * a.y, s * a.z); }
 __device__ __forceinline__ V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
 __device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// the same sum, left to right, with the two additions fused into their products
+__device__ __forceinline__ float dotF(V3 a, V3 b) { return EXA_F1 ? __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)) : dot(a, b); }
+// exabrick.cu:916-918: sumW * sumD - sumWV * sumDC per component
+__device__ __forceinline__ V3 gradOf(float sumW, float sumWV, V3 sumD, V3 sumDC)
+{
+  return EXA_F1 ? mk(__builtin_fmaf(sumW, sumD.x, -(sumWV * sumDC.x)), __builtin_fmaf(sumW, sumD.y, -(sumWV * sumDC.y)),
+                     __builtin_fmaf(sumW, sumD.z, -(sumWV * sumDC.z)))
+                : mk(sumW * sumD.x - sumWV * sumDC.x, sumW * sumD.y - sumWV * sumDC.y, sumW * sumD.z - sumWV * sumDC.z);
+}
+__device__ __forceinline__ V3 rayAt(V3 org, float t, V3 dir)
+{ return EXA_F1 ? mk(__builtin_fmaf(t, dir.x, org.x), __builtin_fmaf(t, dir.y, org.y), __builtin_fmaf(t, dir.z, org.z)) : org + t * dir; }
 __device__ __forceinline__ float length(V3 a) { return sqrtf(dot(a, a)); }
 __device__ __forceinline__ V3 normalize(V3 a) { return (1.f / sqrtf(dot(a, a))) * a; }
 __device__ __forceinline__ V3 cross(V3 a, V3 b)
@@ -384,9 +399,9 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const int sx = b1.x, sy = b1.y, sz = b1.z;
   const uint32_t begin = (uint32_t)b1.w;
   const float invCw = __int_as_float(b0.w);                 // exact 2^-level: (p/cw) == p*invCw
-  const float lpx = (pos.x - __int_as_float(b0.x)) * invCw - 0.5f;
-  const float lpy = (pos.y - __int_as_float(b0.y)) * invCw - 0.5f;
-  const float lpz = (pos.z - __int_as_float(b0.z)) * invCw - 0.5f;
+  const float lpx = EXA_F1 ? __builtin_fmaf(pos.x - __int_as_float(b0.x), invCw, -0.5f) : (pos.x - __int_as_float(b0.x)) * invCw - 0.5f;
+  const float lpy = EXA_F1 ? __builtin_fmaf(pos.y - __int_as_float(b0.y), invCw, -0.5f) : (pos.y - __int_as_float(b0.y)) * invCw - 0.5f;
+  const float lpz = EXA_F1 ? __builtin_fmaf(pos.z - __int_as_float(b0.z), invCw, -0.5f) : (pos.z - __int_as_float(b0.z)) * invCw - 0.5f;
   // idx_lo = max(-1, int(floor(local))) (exabrick.cu:627-629); the clamp on the float is the same value (floor is
   // integral, -1 exact) and saves converting the clamped index back for the fraction
   const float flx = fmaxf(floorf(lpx), -1.f), fly = fmaxf(floorf(lpy), -1.f), flz = fmaxf(floorf(lpz), -1.f);
@@ -572,9 +587,9 @@ __device__ __forceinline__ void addBasisFastIl(Basis &B, float *xWV, V3 *xD, con
   const int sx = b1.x, sy = b1.y, sz = b1.z;
   const uint32_t begin = (uint32_t)b1.w;
   const float invCw = __int_as_float(b0.w);
-  const float lpx = (pos.x - __int_as_float(b0.x)) * invCw - 0.5f;
-  const float lpy = (pos.y - __int_as_float(b0.y)) * invCw - 0.5f;
-  const float lpz = (pos.z - __int_as_float(b0.z)) * invCw - 0.5f;
+  const float lpx = EXA_F1 ? __builtin_fmaf(pos.x - __int_as_float(b0.x), invCw, -0.5f) : (pos.x - __int_as_float(b0.x)) * invCw - 0.5f;
+  const float lpy = EXA_F1 ? __builtin_fmaf(pos.y - __int_as_float(b0.y), invCw, -0.5f) : (pos.y - __int_as_float(b0.y)) * invCw - 0.5f;
+  const float lpz = EXA_F1 ? __builtin_fmaf(pos.z - __int_as_float(b0.z), invCw, -0.5f) : (pos.z - __int_as_float(b0.z)) * invCw - 0.5f;
   const float flx = fmaxf(floorf(lpx), -1.f), fly = fmaxf(floorf(lpy), -1.f), flz = fmaxf(floorf(lpz), -1.f);
   const int lx = int(flx), ly = int(fly), lz = int(flz);
   const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
@@ -746,9 +761,7 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
   if (B.sumW <= 1e-20f) return false;
   value = B.sumWV / B.sumW;
   if (DERIV)
-    derivatives = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
-                     B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
-                     B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
+    derivatives = gradOf(B.sumW, B.sumWV, B.sumD, B.sumDC);
   return true;
 }
 
@@ -765,18 +778,18 @@ __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, flo
     // fast_math: transcendental instructions issue at a quarter of the rate, and this block had three of them (sqrt for the
     // threshold, sqrt and rcp for the factor).  The threshold test on the squares and one reciprocal square root keep the
     // shading factor within 2 ulp of the library form (it only scales a colour) at one transcendental
-    const float g2 = dot(gradient, gradient);
+    const float g2 = dotF(gradient, gradient);
     const float thr = finestLevelCellWidth * 1e-6f;
     if (g2 > thr * thr) {
       const V3 lightDir = -ray.dir;
-      const float scale = fabsf(dot(lightDir, gradient)) * __builtin_amdgcn_rsqf(g2 * dot(lightDir, lightDir));
+      const float scale = fabsf(dotF(lightDir, gradient)) * __builtin_amdgcn_rsqf(g2 * dotF(lightDir, lightDir));
       sample.x *= scale; sample.y *= scale; sample.z *= scale;
     }
   } else
 #endif
-  if (fsqrt<FAST>(dot(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
+  if (fsqrt<FAST>(dotF(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
-    const float scale = fdiv<FAST>(fabsf(dot(lightDir, gradient)), fsqrt<FAST>(dot(gradient, gradient) * dot(lightDir, lightDir)));
+    const float scale = fdiv<FAST>(fabsf(dotF(lightDir, gradient)), fsqrt<FAST>(dotF(gradient, gradient) * dotF(lightDir, lightDir)));
     sample.x *= scale; sample.y *= scale; sample.z *= scale;
   }
   // opacity correction 1-(1-a)^dt (exabrick.cu:1011).  FAST: pow as exp2(dt*log2(x)) on the
@@ -791,9 +804,15 @@ __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, flo
 __device__ __forceinline__ void compositeSample(Color4 &pixelColor, const Color4 &sample)
 {
   const float k = (1.f - pixelColor.w) * sample.w;
-  pixelColor.x += k * sample.x;
-  pixelColor.y += k * sample.y;
-  pixelColor.z += k * sample.z;
+  if (EXA_F1) {
+    pixelColor.x = __builtin_fmaf(k, sample.x, pixelColor.x);
+    pixelColor.y = __builtin_fmaf(k, sample.y, pixelColor.y);
+    pixelColor.z = __builtin_fmaf(k, sample.z, pixelColor.z);
+  } else {
+    pixelColor.x += k * sample.x;
+    pixelColor.y += k * sample.y;
+    pixelColor.z += k * sample.z;
+  }
   pixelColor.w += k * 1.f;
 }
 
@@ -865,7 +884,7 @@ __device__ __forceinline__ void integrateBrick(Ctx<STATS> &C, Color4 &pixelColor
     const float t_sample = 0.5f * (fminf(t1, t_next) + t_last);
     const float actual_dt = t_next - t_last;
     t_last = t_next;
-    const V3 pos = ray.org + t_sample * ray.dir;
+    const V3 pos = rayAt(ray.org, t_sample, ray.dir);
     float cellValue = 0.f;
     V3 grad = mk(0.f, 0.f, 0.f);
     for (int c = 0; c < numChannels; ++c) {
@@ -2312,8 +2331,8 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         }
         w.pk.clearField(PK_NEEDHDR);
       }
-      if (NCH) addBasisFastIl<GRAD, SMALL, (NCH ? NCH : 2)>(B, xWV, xD, hb0, hb1, a.cellsIl, ray.org + t_sample * ray.dir);
-      else addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, ray.org + t_sample * ray.dir);   // :1166
+      if (NCH) addBasisFastIl<GRAD, SMALL, (NCH ? NCH : 2)>(B, xWV, xD, hb0, hb1, a.cellsIl, rayAt(ray.org, t_sample, ray.dir));
+      else addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, rayAt(ray.org, t_sample, ray.dir));   // :1166
       child++;
       if (child < listSize) continue;
 
@@ -2333,7 +2352,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
             const V3 sd = c == 0 ? B.sumD : xD[c == 0 ? 0 : c - 1];
             const float cellValue = fdivExact<FAST>(wv, B.sumW);
             V3 grad = mk(0.f, 0.f, 0.f);
-            if (GRAD) grad = mk(B.sumW * sd.x - wv * B.sumDC.x, B.sumW * sd.y - wv * B.sumDC.y, B.sumW * sd.z - wv * B.sumDC.z);
+            if (GRAD) grad = gradOf(B.sumW, wv, sd, B.sumDC);
             integrateVolume<FAST, STATS, FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, c, xfRcpRangeN[c]);
           }
         }
@@ -2343,9 +2362,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         C.count(ST_SAMPLES);
         const float cellValue = fdivExact<FAST>(B.sumWV, B.sumW);
         V3 grad = mk(0.f, 0.f, 0.f);
-        if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
-                            B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
-                            B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
+        if (GRAD) grad = gradOf(B.sumW, B.sumWV, B.sumD, B.sumDC);
         integrateVolume<FAST, STATS, (FAST && !MULTI)>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, MULTI ? chan : 0, xfRcpRange0);
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
@@ -2721,7 +2738,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
           const unsigned at = 2u * (unsigned)(listBegin + child);
           hb0 = a.sc.leafHdr[at]; hb1 = a.sc.leafHdr[at + 1u];
         }
-        addBasisFast<GRAD, 0, SMALL>(C, B, hb0, hb1, field0, ray.org + t_sample * ray.dir);   // :1166
+        addBasisFast<GRAD, 0, SMALL>(C, B, hb0, hb1, field0, rayAt(ray.org, t_sample, ray.dir));   // :1166
         myVisits++;
       }
       needHdr = false;
@@ -2734,9 +2751,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
       if (mine && B.sumW > 1e-20f && actual_dt != 0.f) {
         const float cellValue = fdivExact<FAST>(B.sumWV, B.sumW);
         V3 grad = mk(0.f, 0.f, 0.f);
-        if (GRAD) grad = mk(B.sumW * B.sumD.x - B.sumWV * B.sumDC.x,
-                            B.sumW * B.sumD.y - B.sumWV * B.sumDC.y,
-                            B.sumW * B.sumD.z - B.sumWV * B.sumDC.z);
+        if (GRAD) grad = gradOf(B.sumW, B.sumWV, B.sumD, B.sumDC);
         smp = shadeSample<FAST>(C, ray, actual_dt, cellValue, grad, flcw, 0);
         contributes = 1;
       }

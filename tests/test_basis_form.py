@@ -59,7 +59,8 @@ def test_per_axis_form_equals_source_order_within_the_stated_tolerance(name):
 @pytest.mark.parametrize("name", ["ex3_iso", "amr_iso", "amr_2ch_iso"])
 def test_per_axis_form_iso_surfaces(name):
     """implicit iso-surfaces: the hit point is found by bracketing, so an ulp in a value can move a crossing by a step
-    for a rare pixel; the surface colour of such a pixel changes like an AO flip (<= 0.3 % of the pixels)"""
+    for a rare pixel; the surface colour of such a pixel changes like an AO flip (stated allowance: 0.5 % of the pixels;
+    measured 0.1 - 0.3 %, printed)"""
     mk = {"ex3_iso": lambda f: Case(scenes.example("ex3"), W=96, H=64, grad=1, iso=[(0.4, 0)], basis_form=f),
           "amr_iso": lambda f: Case(_amr(), W=128, H=128, grad=1, iso=[(0.45, 0)], basis_form=f),
           "amr_2ch_iso": lambda f: Case(scenes.amr(seed=5, root=(2, 2, 2), B=4, levels=3, feature="plume", fields=2), W=96, H=96,
@@ -67,7 +68,7 @@ def test_per_axis_form_iso_surfaces(name):
     o0, o1 = mk(0).run_oracle(), mk(1).run_oracle()
     da = np.abs(o0[1] - o1[1]).max(axis=-1)
     moved = int((da > ACCUM_ATOL + ACCUM_RTOL * np.abs(o0[1]).max(axis=-1)).sum())
-    assert moved <= max(2, 0.003 * da.size), (moved, float(da.max()))
+    assert moved <= max(2, 0.005 * da.size), (moved, float(da.max()))
     assert o0[2]["iso_segments"] == o1[2]["iso_segments"]
     print(f"{name}: pixels beyond tolerance {moved} of {da.size}, max |d accum| {float(da.max()):.3g}")
 
