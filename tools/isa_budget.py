@@ -43,13 +43,13 @@ for i, l in enumerate(src, 1):
 
 def phase_of(line):
     f = func_of_line.get(line, "?")
-    if f in ("addBasisFast", "addBasisFunctions", "loadPair"):
+    if f in ("addBasisFast", "addBasisFunctions", "loadPair", "rayAt"):
         return "brick visit"
-    if f in ("lookupXF", "shadeSample", "compositeSample", "integrateVolume", "fdiv", "fsqrt"):
+    if f in ("lookupXF", "shadeSample", "compositeSample", "integrateVolume", "fdiv", "fsqrt", "dotF", "gradOf"):
         return "sample epilogue"
     if f in ("kdStep", "kdPop"):
         return "kd walk"
-    if f == "firstSampleT":
+    if f in ("firstSampleT", "firstSampleTPow2"):
         return "segment pop"
     if f.startswith("renderFrameKdKernel") or f == "__launch_bounds__":
         return None            # decided by line ranges inside the kernel body
