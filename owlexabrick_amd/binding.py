@@ -108,7 +108,7 @@ def lib():
             # not built yet: try to build the HIP module (hipcc cross-compiles without a GPU); never a CPU fallback
             import subprocess
             try:
-                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s"])
+                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"])
             except Exception as e:  # noqa: BLE001
                 raise RuntimeError(f"{LIB_PATH} not found and building it failed ({e}); run "
                                    "__graft_entry__.build(); there is no CPU fallback") from e
