@@ -103,6 +103,7 @@ typedef struct ExaHipScene {
   const ExaKdNode      *kdNodes;       /* optional (may be NULL) */
   uint64_t              numKdNodes;
   int32_t               kdRoot;        /* reference of the root (a leaf ref for a one-region scene) */
+  /* (added in round 4, at the end: a caller that fills the struct by hand zero-initialises it first) */
   int32_t               allowEmptyCells; /* the reference's compile-time option ALLOW_EMPTY_CELLS (CMakeLists.txt:70-73, default
                                           OFF) as a property of the scene: scalars equal to EXA_EMPTY_CELL_POISON_VALUE are
                                           "no cell here" and addBasisFunctions skips them (programs/exabrick.cu:614-618) */
