@@ -17,7 +17,7 @@ gcc $SAN -fsanitize=float-cast-overflow -fno-sanitize-recover=float-cast-overflo
 CS="$ROOT/owlexabrick_amd/csrc"
 /opt/rocm/bin/hipcc $SAN -std=c++17 -fPIC -ffp-contract=off -c "$CS/exa_prep.cpp" -o "$D/exa_prep.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$D/libexa_hip.so" \
-    "$CS/exa_kernels.o" "$CS/exa_lbvh.o" "$CS/exa_module.o" "$D/exa_prep.o" -lpthread 2>/dev/null
+    "$CS/exa_kernels_f0.o" "$CS/exa_kernels_f1.o" "$CS/exa_kernels_f0e.o" "$CS/exa_lbvh.o" "$CS/exa_module.o" "$D/exa_prep.o" -lpthread 2>/dev/null
 GCC_RT="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 CLANG_RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.asan-x86_64.so" | head -1)
 export ASAN_OPTIONS=detect_leaks=0
@@ -30,7 +30,17 @@ import test_builder
 test_builder.EXE = D + "/exaBuilder"
 import fuzz_builder
 fails = sum(bool(fuzz_builder.check(s)[0]) for s in range(300))
-print(f"exaBuilder under ASan+UBSan: {fails} failed of 300")
+# ... and with --allow-empty-cells on cell sets with a quarter of the cells removed
+import numpy as np
+from owlexabrick_amd import scenes
+from oracle import builder_oracle as bo
+for s in range(40):
+    rng = np.random.default_rng(0x5A17 + s)
+    full = test_builder.cells_of(scenes.amr(seed=3 + s, root=(2, 2, 1), B=4, levels=2))
+    cells = full[rng.uniform(size=len(full)) > 0.25]
+    r, data = test_builder.run_builder(cells, ["--allow-empty-cells"], max_leaf_width=6)
+    fails += int(r.returncode != 0 or data != bo.to_bricks_file_bytes(bo.build_bricks(cells, bo.SAH_ALIKE, max_leaf_width=6, allow_empty_cells=True)))
+print(f"exaBuilder under ASan+UBSan: {fails} failed of 340")
 sys.exit(1 if fails else 0)
 PY
 LD_PRELOAD="$GCC_RT" python3 - "$D" <<'PY'
@@ -55,6 +65,17 @@ sys.path.insert(0, '.'); sys.path.insert(0, '..')
 import fuzz_prep
 fails = sum(bool(fuzz_prep.check(s)[0]) for s in range(600))
 print(f"host preparation (exa_prep.cpp) under ASan+UBSan: {fails} failed of 600")
+# ... and with cells missing (ALLOW_EMPTY_CELLS): prep == oracle byte for byte on 100 scenes with holes
+from fuzz_cases import random_case
+from owlexabrick_amd import binding, scenes
+from oracle import pyoracle as po
+for s in range(100):
+    sc = scenes.with_empty_cells(random_case(s, grids=(s % 2 == 0))[0].scene, fraction=0.2, seed=s)
+    S = po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields, allow_empty_cells=True)
+    P = binding.Prep(sc, num_threads=3, allow_empty_cells=True)
+    fails += int(P.scalars().tobytes() != S.scalars().tobytes() or P.regions().tobytes() != S.regions().tobytes())
+    P.close()
+print(f"host preparation with empty cells under ASan+UBSan: {fails} failed of 100")
 sys.exit(1 if fails else 0)
 PY
 /opt/rocm/bin/hipcc $SAN -std=c++17 -shared-libsan -o "$D/exaRender" "$ROOT/owlexabrick_amd/host/exaRender.cpp" "$ROOT/owlexabrick_amd/host/exa_host.cpp" \
