@@ -7,7 +7,7 @@
   C5  exajet-like, full  4096x4096 DVR + iso-surface + AO, frames 0..15 accumulated
 
 For each: (a) the oracle under the tolerance of tests/common.py — on the WHOLE frame for C2, C3 and C4 (every pixel
-of the 1024^2 / 2048^2 frame; 16 host threads render them in about 2 / 20 / 30 s), on a 96x96 crop where the rays are
+of the 1024^2 / 2048^2 frame; 16 host threads render them in about 2 / 20 / 30 s), on a 256x256 crop where the rays are
 dense and on one across the silhouette for C5 (16 accumulated 4096^2 frames); (b) properties that need no oracle at full size: the kd walk and the LBVH restart pick
 the same segments (bit-equal frames with the library powf), space skipping is image-neutral (KAT-7), launch order,
 launch-order feedback and the wide march never change a pixel (also as rank 0 of 8, where the wide march engages)."""
@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 CROP = 96
 
 
-def _windows(acc, W, H):
+def _windows(acc, W, H, CROP=CROP):
     """a fully covered CROP x CROP window nearest the image centre, and the one whose coverage is closest to one half
     (the silhouette), both on a 32-pixel grid; deterministic functions of the rendered frame"""
     cov = (acc[..., :3].sum(axis=-1) > 0).astype(np.float64)
@@ -136,8 +136,8 @@ def _properties(cfg, frames=1, lbvh=True):
     return base
 
 
-def _oracle_crops(cfg, base_acc, frames=1, ao=0, what=""):
-    wins = _windows(base_acc, cfg.case.W, cfg.case.H)
+def _oracle_crops(cfg, base_acc, frames=1, ao=0, what="", crop=CROP):
+    wins = _windows(base_acc, cfg.case.W, cfg.case.H, crop)
     for k, win in wins.items():
         acc = cfg.oracle_frames(win, frames)
         _check_crop(base_acc, acc, win, frames, ao, f"{what} {k} {win}")
@@ -220,7 +220,7 @@ def test_c5_exajet_full_4096_dvr_iso_ao_16_frames(exajet_full):
     cfg.R.setOption("tile_feedback", 1)
     cfg.R.setOption("wide_march", 1)
     base = cfg.render_frames(16)
-    _oracle_crops(cfg, base[1], frames=16, ao=1, what="C5")
+    _oracle_crops(cfg, base[1], frames=16, ao=1, what="C5", crop=256)      # two 256 x 256 windows x 16 accumulated frames
     # the iso-surface is really marched (the DVR in front of it leaves little of it visible with the default TF)
     cfg.R.updateFrameID(0)
     _, st = cfg.R.renderStats()
