@@ -9,6 +9,7 @@ LIBS="$ROOT/build/variants"
 OUT="$ROOT/gpurun_out/variants"
 CS="$ROOT/owlexabrick_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function"
+KFLAGS=${KFLAGS--mllvm -amdgpu-sched-strategy=max-ilp}     # the Makefile's flags for the kernel translation units (KFLAGS= for none)
 mode=$1; shift
 if [ "$mode" = build ]; then
   mkdir -p "$OUT" "$LIBS"
@@ -16,9 +17,9 @@ if [ "$mode" = build ]; then
     name=${spec%%:*}; defs=${spec#*:}
     (
       d="$OUT/obj_$name"; mkdir -p "$d"
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -DEXA_BASIS_FORM=0 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f0.o" &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -DEXA_BASIS_FORM=1 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f1.o" &&
-      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -DEXA_BASIS_FORM=0 -DEXA_EMPTY_CELLS=1 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f0e.o" &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $KFLAGS $defs -DEXA_BASIS_FORM=0 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f0.o" &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $KFLAGS $defs -DEXA_BASIS_FORM=1 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f1.o" &&
+      /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $KFLAGS $defs -DEXA_BASIS_FORM=0 -DEXA_EMPTY_CELLS=1 -c "$CS/exa_kernels.hip" -o "$d/exa_kernels_f0e.o" &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -c "$CS/exa_lbvh.hip" -o "$d/exa_lbvh.o" &&
       /opt/rocm/bin/hipcc --offload-arch=gfx950 $FLAGS $defs -x hip -c "$CS/exa_module.cpp" -o "$d/exa_module.o" &&
       /opt/rocm/bin/hipcc $FLAGS -c "$CS/exa_prep.cpp" -o "$d/exa_prep.o" &&
