@@ -55,9 +55,9 @@ def check(seed):
             if not _same(_frames(R), base):
                 bad.append(f"wide_march {lanes}")
         R.setOption("wide_march", 1)
-    # round 3: where the cells lie in memory and how a frame with surfaces is launched
+    # round 3: where the cells lie in memory and how a frame with surfaces is launched (round 4: ao_defer 2 = sorted AO rays)
     for key, val in (("brick_order", 1), ("interleave", 0), ("addr64", 1), ("prepass_split", 0), ("brick_order", 0), ("interleave", 1),
-                     ("prepass_split", 1), ("addr64", 0), ("ao_defer", 0), ("ao_defer", 1)):
+                     ("prepass_split", 1), ("addr64", 0), ("ao_defer", 0), ("ao_defer", 2), ("ao_defer", 1)):
         R.setOption(key, val)
         for k in range(2 if key == "prepass_split" else 1):      # the plan changes after its measuring frame
             if not _same(_frames(R), base):
