@@ -6,23 +6,7 @@
 
 #include <vector>
 
-// ---- build-time switches shared by the module and the kernels (one default for both translation units: the
-//      host writes the march headers the kernel interprets) ----
-#ifndef EXA_OPT_POP1
-#define EXA_OPT_POP1 1
-#endif
-#ifndef EXA_OPT_ADDR32
-#define EXA_OPT_ADDR32 1
-#endif
-#ifndef EXA_OPT_MUL24
-#define EXA_OPT_MUL24 1
-#endif
-#ifndef EXA_OPT_FHDR
-#define EXA_OPT_FHDR 1
-#endif
-#ifndef EXA_OPT_DTPOW2
-#define EXA_OPT_DTPOW2 1
-#endif
+// ---- build-time constants shared by the module and the kernels ----
 #ifndef EXA_MARCH_WAVES
 #define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup)
 #endif
@@ -46,35 +30,12 @@
 #ifndef EXA_AO_ISO_WAVES
 #define EXA_AO_ISO_WAVES 6      // waves per SIMD of the deferred AO rays' kernel (iso-only frames): the rays are latency-bound marches
 #endif
-#ifndef EXA_OPT_SORG
-#define EXA_OPT_SORG 1        // march: the (wave-uniform) ray origin in scalar registers (three VGPRs less to keep alive; time within noise)
-#endif
-#ifndef EXA_OPT_BURSTPRIO
-#define EXA_OPT_BURSTPRIO 1   // march: walk bursts at raised wave priority (s_setprio 1; 0 = off).  A burst is a chain of dependent node
-                              // loads during which every lane of the wave waits.  C4 22.56 -> 22.38 ms (priority 1 / 2 / 3 alike), inside camera
-                              // 32.82 -> 32.50, three channels 41.2 -> 40.9, C3 + iso unchanged; the segment pops at raised priority as well
-                              // gave the gain back (removed)
-#endif
-#ifndef EXA_OPT_EPIPRIO
-#define EXA_OPT_EPIPRIO 1     // march: sample epilogue at raised wave priority as well (its LDS reads and transcendentals are a dependent chain):
-                              // C4 22.13 -> 21.94 ms on top of the burst priority; levels 1 / 2 / 3 of either alike
-#endif
-#ifndef EXA_OPT_RSQ
-#define EXA_OPT_RSQ 1         // fast_math: gradient-shading factor with one transcendental (rsq) instead of three (sqrt, sqrt, rcp)
-#endif
-#ifndef EXA_OPT_LANE_MORTON
-#define EXA_OPT_LANE_MORTON 1 // lanes of a wave cover their 8x8 pixel block along a Morton curve (quad = 2x2 pixels) instead of row by row
-#endif
 #ifndef EXA_EMPTY_CELLS
 #define EXA_EMPTY_CELLS 0     // this translation unit of exa_kernels.hip skips corners whose cell holds the poison value
 #endif
 #ifndef EXA_BASIS_FORM
 #define EXA_BASIS_FORM 0      // which association of the basis sums this translation unit of exa_kernels.hip is compiled for
 #endif
-#ifndef EXA_OPT_MED3
-#define EXA_OPT_MED3 1        // v_med3_i32 for the cell clamps (inline asm; -0.6 % on C4)
-#endif
-
 namespace exa {
 
 // One LBVH node = 64 bytes = four 16-byte loads.  Both children's boxes live in

@@ -9,15 +9,15 @@
 #include "exa_device.h"
 #include <cfloat>
 
-// Round-2 instruction trims of the kd march (profiles/r02_isa_budget.txt); each keeps every pixel bit for bit and can
-// be switched off at build time for A/B timing (-DEXA_OPT_...=0):
-//   POP1    one pop site in the kd step instead of five inlined copies
-//   ADDR32  cell loads as uniform base + 32-bit byte offset (global_load saddr form) when a field is < 4 GiB
-//   MUL24   24-bit integer multiplies in the cell address (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate)
-//   FHDR    march header carries float(lower) and 2^-level: no conversions / exponent build per visit; the -1 clamp
-//           of the cell index is done on the float
-//   DTPOW2  first sample of a segment: x / dt as x * (1/dt) when dt is a power of two (exact)
-//   MED3    clamp(l, 0, size-1) as one v_med3_i32
+// Instruction trims of the kd march that keep every pixel bit for bit (measured one by one in rounds 2-4,
+// profiles/design_history_r01_r03.md, profiles/r04_experiments.txt; the build-time switches they were A/B-timed with are gone):
+//   one pop site in the kd step instead of five inlined copies
+//   cell loads as uniform base + 32-bit byte offset (global_load saddr form) when a field is < 4 GiB (SMALL)
+//   24-bit integer multiplies in the cell address (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate) (SMALL)
+//   the march header carries float(lower) and 2^-level: no conversions / exponent build per visit; the -1 clamp
+//   of the cell index is done on the float
+//   first sample of a segment: x / dt as x * (1/dt) when dt is a power of two (exact)
+//   clamp(l, 0, size-1) as one v_med3_i32
 #if EXA_BASIS_FORM == 0 && EXA_EMPTY_CELLS
 #define EXA_FORM_NS form0e
 #elif EXA_BASIS_FORM == 0
@@ -125,18 +125,13 @@ __device__ __forceinline__ float clockHeat(float clockScale, unsigned long long 
 }
 struct Color4 { float x, y, z, w; };
 
-// lane -> pixel inside the wave's 8x8 block.  EXA_OPT_LANE_MORTON: along a Morton curve, so that a quad of lanes is a 2x2
+// lane -> pixel inside the wave's 8x8 block: along a Morton curve, so that a quad of lanes is a 2x2
 // pixel block and 16 lanes a 4x4 block instead of 4x1 / 8x2 strips: the vector memory path handles a wave's gather
 // lane group by lane group and merges the lanes of a group that fall into the same cache line, and the march is bound by
 // the number of such accesses (TCP_TOTAL_CACHE_ACCESSES = one per clock and CU over the whole frame) —
 // closer pixels share more lines.  Pixels do not depend on which lane renders them.
-#if EXA_OPT_LANE_MORTON
 __device__ __forceinline__ int laneX(int lane) { return (lane & 1) | ((lane >> 1) & 2) | ((lane >> 2) & 4); }
 __device__ __forceinline__ int laneY(int lane) { return ((lane >> 1) & 1) | ((lane >> 2) & 2) | ((lane >> 3) & 4); }
-#else
-__device__ __forceinline__ int laneX(int lane) { return lane & 7; }
-__device__ __forceinline__ int laneY(int lane) { return lane >> 3; }
-#endif
 
 // per-thread view of the kernel state.  STATS: 0 = the shipped kernel, 1 = work counters (sample for sample the
 // oracle's), 2 = wave time by phase only (the shipped code plus a clock read at every phase change)
@@ -394,7 +389,6 @@ template <bool DERIV, int STATS, bool SMALL>
 __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4 b0, const int4 b1,
                                              const float *__restrict__ field, V3 pos)
 {
-#if EXA_OPT_FHDR
   // march header (exa_module: leafHdr): b0 = (float(lower.xyz), 2^-level) as float bits, b1 = (size.xyz, begin)
   const int sx = b1.x, sy = b1.y, sz = b1.z;
   const uint32_t begin = (uint32_t)b1.w;
@@ -408,23 +402,10 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const int lx = int(flx), ly = int(fly), lz = int(flz);
   const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
   const float fx = lpx - flx, fy = lpy - fly, fz = lpz - flz;
-#else
-  // b0 = (lower.xyz, size.x)  b1 = (size.y, size.z, level, begin): the ExaBrick record itself
-  const int sx = b0.w, sy = b1.x, sz = b1.y;
-  const uint32_t begin = (uint32_t)b1.w;
-  const float invCw = __int_as_float((127 - b1.z) << 23);   // exact 2^-level
-  const float lpx = (pos.x - float(b0.x)) * invCw - 0.5f;
-  const float lpy = (pos.y - float(b0.y)) * invCw - 0.5f;
-  const float lpz = (pos.z - float(b0.z)) * invCw - 0.5f;
-  const int lx = max(-1, int(floorf(lpx))), ly = max(-1, int(floorf(lpy))), lz = max(-1, int(floorf(lpz)));
-  const int hx = lx + 1, hy = ly + 1, hz = lz + 1;
-  const float fx = lpx - float(lx), fy = lpy - float(ly), fz = lpz - float(lz);
-#endif
   // 0 <= l < size as one unsigned compare (l >= -1, sizes > 0)
   const bool vlx = (uint32_t)lx < (uint32_t)sx, vhx = hx < sx;
   const bool vly = (uint32_t)ly < (uint32_t)sy, vhy = hy < sy;
   const bool vlz = (uint32_t)lz < (uint32_t)sz, vhz = hz < sz;
-#if EXA_OPT_MED3
   // clamp(l, 0, size-1) as one v_med3_i32 (sizes >= 1, so 0 <= size-1 and the median IS the clamp); the compiler
   // cannot prove the bound order and emits v_max + v_min
   auto med3 = [](int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
@@ -432,18 +413,12 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const int cyl = med3(ly, 0, sy - 1), cyh = min(hy, sy - 1);
   const int czl = med3(lz, 0, sz - 1), czh = min(hz, sz - 1);
   const int bx = med3(lx, 0, max(sx - 2, 0));
-#else
-  const int cxl = min(max(lx, 0), sx - 1), cxh = min(hx, sx - 1);
-  const int cyl = min(max(ly, 0), sy - 1), cyh = min(hy, sy - 1);
-  const int czl = min(max(lz, 0), sz - 1), czh = min(hz, sz - 1);
-  const int bx = min(max(lx, 0), max(sx - 2, 0));
-#endif
   float s000, s100, s010, s110, s001, s101, s011, s111;
   {
     // (eight 4-byte loads instead of four 8-byte pair loads would save the pair base, two compares and eight
     // selects, ~10 VALU per visit — measured on C4: 26.1 instead of 22.5 ms, the L1 request rate matters too)
     uint32_t rowLL, rowHL, rowLH, rowHH;                      // cell index of the pair's first cell, per (y,z) row
-    if (EXA_OPT_MUL24 && SMALL) {
+    if (SMALL) {
       // SMALL: every factor below 2^24 and every product below 2^32 (checked per scene on the host)
       // (the compiler turns this one __umul24 into the quarter-rate v_mul_lo_u32; forcing v_mul_u32_u24 with inline asm
       // measured 22.25 against 22.19 ms — the asm pins the schedule — so it stays)
@@ -462,7 +437,7 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
     // aligned), then pick the clamped low/high cell out of the pair
     const bool lFirst = cxl == bx, hFirst = cxh == bx;
     Pair pLL, pHL, pLH, pHH;
-    if (EXA_OPT_ADDR32 && SMALL) {
+    if (SMALL) {
       // SMALL: a field is below 4 GiB: wave-uniform base + 32-bit byte offset per lane (no 64-bit address arithmetic)
       const char *base = reinterpret_cast<const char *>(field);
       pLL = *reinterpret_cast<const Pair *>(base + (rowLL << 2)); pHL = *reinterpret_cast<const Pair *>(base + (rowHL << 2));
@@ -583,7 +558,6 @@ template <bool DERIV, bool SMALL, int NCH>
 __device__ __forceinline__ void addBasisFastIl(Basis &B, float *xWV, V3 *xD, const int4 b0, const int4 b1,
                                                const float *__restrict__ cellsIl, V3 pos)
 {
-  static_assert(EXA_OPT_FHDR, "the interleaved march reads the float march headers");
   const int sx = b1.x, sy = b1.y, sz = b1.z;
   const uint32_t begin = (uint32_t)b1.w;
   const float invCw = __int_as_float(b0.w);
@@ -603,7 +577,7 @@ __device__ __forceinline__ void addBasisFastIl(Basis &B, float *xWV, V3 *xD, con
   const int czl = med3(lz, 0, sz - 1), czh = min(hz, sz - 1);
   const int bx = med3(lx, 0, max(sx - 2, 0));
   uint32_t rowLL, rowHL, rowLH, rowHH;                      // cell index of the pair's first cell, per (y,z) row
-  if (EXA_OPT_MUL24 && SMALL) {
+  if (SMALL) {
     const uint32_t sxy = __umul24((uint32_t)sx, (uint32_t)sy);
     const uint32_t zl = __umul24((uint32_t)czl, sxy) + (begin + (uint32_t)bx);
     const uint32_t zh = __umul24((uint32_t)czh, sxy) + (begin + (uint32_t)bx);
@@ -747,7 +721,6 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
       const int4 b0 = sc.bricks[2 * brickID], b1 = sc.bricks[2 * brickID + 1];
 #if EXA_BASIS_FORM == 1
       // the per-axis association has one implementation: the brick record is turned into a march header on the fly
-      static_assert(EXA_OPT_FHDR, "form 1 evaluates on the float march headers");
       const int4 h0 = make_int4(__float_as_int(float(b0.x)), __float_as_int(float(b0.y)), __float_as_int(float(b0.z)), (127 - b1.z) << 23);
       const int4 h1 = make_int4(b0.w, b1.x, b1.y, b1.w);
       addBasisFast<DERIV, STATS, false>(C, B, h0, h1, field, pos);
@@ -773,7 +746,6 @@ __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, flo
   Color4 sample = lookupXF<FAST, HAVE_RCP>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic, rcpRange);
   // the reference compares with `int finestLevelCellWidth` * 1e-6f (exabrick.cu:1124,1001); the width is an
   // integer-valued float (a power of two >= 1, checked at scene creation), so the int round trip is the identity
-#if EXA_OPT_RSQ
   if (FAST) {
     // fast_math: transcendental instructions issue at a quarter of the rate, and this block had three of them (sqrt for the
     // threshold, sqrt and rcp for the factor).  The threshold test on the squares and one reciprocal square root keep the
@@ -785,9 +757,7 @@ __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, flo
       const float scale = fabsf(dotF(lightDir, gradient)) * __builtin_amdgcn_rsqf(g2 * dotF(lightDir, lightDir));
       sample.x *= scale; sample.y *= scale; sample.z *= scale;
     }
-  } else
-#endif
-  if (fsqrt<FAST>(dotF(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
+  } else if (fsqrt<FAST>(dotF(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
     const V3 lightDir = -ray.dir;
     const float scale = fdiv<FAST>(fabsf(dotF(lightDir, gradient)), fsqrt<FAST>(dotF(gradient, gradient) * dotF(lightDir, lightDir)));
     sample.x *= scale; sample.y *= scale; sample.z *= scale;
@@ -1627,14 +1597,10 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
     if (!(ISOWALK && hit && t1 < w.tf)) w.ref = EXA_KD_EMPTY;
   }
   if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > walkTmin))) kdPop<STATS, KS, SMALL>(C, w, root, stackF, nodes, ray);
-  // With EXA_OPT_POP1 this is the only pop: a node that leaves nothing to descend into marks the subtree EMPTY and
+  // This is the only pop: a node that leaves nothing to descend into marks the subtree EMPTY and
   // the pop happens here at the start of the lane's next call, in front of that call's node stage — the same
   // sequence of subtrees, with one inlined copy of the pop instead of five for the wave's divergent lanes to run
-#if EXA_OPT_POP1
 #define EXA_KD_POP_LATER() (w.ref = EXA_KD_EMPTY)
-#else
-#define EXA_KD_POP_LATER() kdPop<STATS, KS, SMALL>(C, w, root, stackF, nodes, ray)
-#endif
   // the popped subtree gets its own look at tmin / tmax in the next call
   if (w.ref < 0 || !(w.tf > walkTmin) || (ISOWALK && !(w.tn < walkTmax))) return;
   // SMALL: the node array is below 4 GiB — uniform base + 32-bit byte offset, no 64-bit address per lane
@@ -2196,12 +2162,10 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
     }
     surface_t_hit = ray.tmax;
     ray.org = xfmPoint(fs, ray.org);                                              // :1664-1668
-#if EXA_OPT_SORG
     // the ray origin is the camera position in voxel space: the same value in every lane, so it lives in scalar registers
     ray.org.x = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ray.org.x)));
     ray.org.y = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ray.org.y)));
     ray.org.z = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ray.org.z)));
-#endif
     ray.dir = xfmVector(fs, ray.dir);
     const float dt_scale = length(ray.dir);
     ray.dir = normalize(ray.dir);
@@ -2264,16 +2228,12 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       // (starting a burst only once 2 / 4 / 8 lanes are dry, the dry ones sitting iterations out: 23.4 / 23.8 / 25.0 ms)
       if (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
         C.lap(ST_T_WALK);
-#if EXA_OPT_BURSTPRIO
-        __builtin_amdgcn_s_setprio(EXA_OPT_BURSTPRIO);   // a burst is a chain of dependent node loads with every lane of the wave waiting
-#endif
+        __builtin_amdgcn_s_setprio(1);   // a burst is a chain of dependent node loads with every lane of the wave waiting
         do {
           const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
           if (want) kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
-#if EXA_OPT_BURSTPRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
       }
       if (!haveSeg) {
         // ---- next segment from this lane's queue ----
@@ -2301,7 +2261,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         C.count(ST_SEGMENTS);
         haveSeg = true;
         w.pk.setBit(PK_NEEDHDR);
-        if (EXA_OPT_DTPOW2 && a.invDtPow2 != 0.f)                                   // :1141-1144
+        if (a.invDtPow2 != 0.f)                                   // :1141-1144
           t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float(0x7f000000 - __float_as_int(flcw)), interleavedSamplingOffset);
         else
           t_i = firstSampleT(t0, a.p.dt * flcw, interleavedSamplingOffset);
@@ -2337,9 +2297,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       if (child < listSize) continue;
 
       // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
-#if EXA_OPT_EPIPRIO
-      __builtin_amdgcn_s_setprio(EXA_OPT_EPIPRIO);
-#endif
+      __builtin_amdgcn_s_setprio(1);
       C.lap(ST_T_FINAL);
       C.phase(ST_W_FINAL);
       if (NCH) {
@@ -2367,9 +2325,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0;
-#if EXA_OPT_EPIPRIO
       __builtin_amdgcn_s_setprio(0);
-#endif
       if (MULTI && !NCH) {
         chan++;
         if (chan < numChannels) {
@@ -2491,11 +2447,7 @@ __device__ __forceinline__ void kdCollectStep(Ctx<0> &C, KdWalk &w, const float 
     w.ref = EXA_KD_EMPTY;
   }
   if (w.ref == EXA_KD_EMPTY || (w.ref != EXA_KD_DONE && !(w.tf > winLo))) kdPop(C, w, root, stackF, nodes, ray);
-#if EXA_OPT_POP1
 #define EXA_KD_POP_LATER() (w.ref = EXA_KD_EMPTY)
-#else
-#define EXA_KD_POP_LATER() kdPop(C, w, root, stackF, nodes, ray)
-#endif
   if (w.ref < 0 || !(w.tf > winLo) || !(w.tn < winHi)) return;
   const int4 n = *reinterpret_cast<const int4 *>(nodes + w.ref);
   const float split = __int_as_float(n.x);

@@ -1085,21 +1085,17 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   CREATE_TRY(h->leafList.upload(scene->leafList, scene->leafListSize));
   {
     // march headers along the leaf list (the kd march reads the record at listBegin + child, no id indirection).
-    // EXA_OPT_FHDR: what a brick visit needs, ready to use — float(lower) (the conversion the reference's
+    // What a brick visit needs, ready to use — float(lower) (the conversion the reference's
     // `vec3f(brick.lower)` performs, exabrick.cu:623), 2^-level, the sizes and the first cell's offset
     std::vector<ExaBrick> hdr(scene->leafListSize);
     for (uint64_t i = 0; i < scene->leafListSize; i++) {
       const ExaBrick &B = scene->bricks[scene->leafList[i]];
-#if EXA_OPT_FHDR
       const float lowerF[3] = { float(B.lower[0]), float(B.lower[1]), float(B.lower[2]) };
       const float invCw = std::ldexp(1.f, -B.level);
       ExaBrick &o = hdr[i];
       std::memcpy(&o.lower[0], lowerF, sizeof(lowerF));
       std::memcpy(&o.size[0], &invCw, sizeof(float));
       o.size[1] = B.size[0]; o.size[2] = B.size[1]; o.level = B.size[2]; o.begin = B.begin;
-#else
-      hdr[i] = B;
-#endif
     }
     CREATE_TRY(h->leafHdr.upload(reinterpret_cast<const int4 *>(hdr.data()), hdr.size() * 2));
   }

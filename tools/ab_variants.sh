@@ -1,7 +1,7 @@
 #!/bin/bash
-# Builds libexa_hip variants with different -DEXA_OPT_* switches (here, no GPU needed) into build/variants/ (git-ignored,
+# Builds libexa_hip variants with different -D... build-time constants (exa_device.h: EXA_MARCH_WAVES, EXA_KD_STACK, EXA_SEG_QUEUE ...) (here, no GPU needed) into build/variants/ (git-ignored,
 # travels to the GPU box), and on the GPU box times each with bench.py on C4, twice, interleaved.
-#   tools/ab_variants.sh build  name1:"-DEXA_OPT_X=0 ..." name2:"..."
+#   tools/ab_variants.sh build  name1:"-DEXA_SEG_QUEUE=5 ..." name2:"..."
 #   tools/ab_variants.sh run [bench args]      -> gpurun_out/variants/results.txt
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
