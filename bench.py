@@ -105,7 +105,7 @@ def spawn_ranks(n):
 # the kernels of one frame: the shipped march (STATS template argument 0), its wide variants for critical tiles, and the
 # surfaces pre-pass (iso-surfaces, AO); the counting variants (STATS 1 / 2) are not part of a timed frame
 _B = "(true|false)"
-FRAME_KERNELS = {"march": rf"renderFrameKdKernel<{_B}, {_B}, \d, {_B}, 0, {_B}(, \d)?>|renderFrameKernel<{_B}, {_B}, 0>",   # <GRAD, FAST, MULTI, SURF, STATS, SMALL, NCH> / <GRAD, ISO, STATS>
+FRAME_KERNELS = {"march": rf"renderFrameKdKernel<{_B}, {_B}, \d, {_B}, 0, {_B}(, \d)?(, {_B})?>|renderFrameKernel<{_B}, {_B}, 0>",   # <GRAD, FAST, MULTI, SURF, STATS, SMALL, NCH, ROPE> / <GRAD, ISO, STATS>
                  "march_wide": r"renderFrameKdWideKernel<",
                  "surfaces_prepass": rf"surfacePrepassKdKernel<0, {_B}, {_B}>",                                          # <STATS, ISO_ONLY, AO_DEFER>
                  "ao_rays": r"aoRaysKdKernel<"}
@@ -115,12 +115,18 @@ VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0       # G wave64-VALU instructions / s: 1
 F32_VECTOR_PEAK_TFLOPS = 157.3               # MI355X_MICROARCH.md: fp32 vector peak (FMA counted as 2)
 
 
-def pmc_frame_totals(csv_files, classes=FRAME_KERNELS, frames=None):
+class PmcBracketError(RuntimeError):
+    pass
+
+
+def pmc_frame_totals(csv_files, classes=FRAME_KERNELS, frames=None, need_bracket=False):
     """rocprofv3 counter_collection CSVs -> ({kernel class: {counter: mean per FRAME}}, frames).  A dispatch's value is the
     sum of its rows (one row per counter instance: XCD, channel, ...).  With two marker dispatches in the list (PMC_MARKER)
     only the dispatches between them count — the timed frames, without warm-up, cost-measurement and counting frames —
-    and `frames` is how many frames the run put there.  Without markers every dispatch counts and a frame is one dispatch
-    of the "march" class (true for frames that launch the march once: no split pre-pass plan)."""
+    and `frames` is how many frames the run put there (the caller knows: steps x spp; a frame may launch the march more
+    than once — the split pre-pass plan, wide tiles — so dispatches cannot be counted instead).  Without markers every
+    dispatch counts and a frame is one dispatch of the "march" class (only true for frames that launch the march once);
+    need_bracket turns a missing bracket, or a missing frame count, into a PmcBracketError instead of that fallback."""
     import csv
     import re
     rows = []
@@ -132,6 +138,9 @@ def pmc_frame_totals(csv_files, classes=FRAME_KERNELS, frames=None):
         if PMC_MARKER in name:
             marks.setdefault(f, set()).add(did)
     bracket = {f: (min(m), max(m)) for f, m in marks.items() if len(m) >= 2}
+    if need_bracket and not (bracket and frames):
+        raise PmcBracketError(f"the timed frames are not bracketed: {sum(len(m) for m in marks.values())} marker dispatch(es) "
+                              f"in {len(csv_files)} file(s), frames={frames}")
     tot, disp = {}, {}
     for f, did, name, counter, value in rows:
         if bracket and not (f in bracket and bracket[f][0] < did < bracket[f][1]):
@@ -167,7 +176,7 @@ def live_pmc(child_args, seconds=300.0, extra_env=None, frames=None):
               "EXA_BENCH_FORCE_DIST", "EXA_BENCH_SHARD", "EXA_BENCH_SPAWNED", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     env.update(extra_env or {})
-    merged, frames = {}, 0
+    merged = {}
     try:
         for i, counters in enumerate(PMC_PASSES):
             cmd = [exe, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(out_dir, f"pass{i}"), "--",
@@ -183,8 +192,15 @@ def live_pmc(child_args, seconds=300.0, extra_env=None, frames=None):
             if p.returncode != 0:
                 tail = (err or b"").decode(errors="replace").strip().splitlines()[-1:] or [""]
                 return None, f"pass {i} ({' '.join(counters)}) exited with {p.returncode}: {tail[0][:200]}"
-            tot, frames = pmc_frame_totals(glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True),
-                                           frames=frames)
+            csvs = glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True)
+            if os.environ.get("EXA_BENCH_KEEP_PMC_CSV"):             # keep the raw lists (tests/golden fixtures, debugging)
+                for n_, f_ in enumerate(csvs):
+                    shutil.copy(f_, os.path.join(os.environ["EXA_BENCH_KEEP_PMC_CSV"], f"pass{i}_{n_}_counter_collection.csv"))
+            try:
+                # the child was told to bracket its timed frames (EXA_BENCH_MARKERS): no bracket = no figure, not a guess
+                tot, frames = pmc_frame_totals(csvs, frames=frames, need_bracket=True)
+            except PmcBracketError as e:
+                return None, f"pass {i} ({' '.join(counters)}): {e}"
             for c in counters:
                 if c not in tot.get("march", {}):
                     return None, f"pass {i}: no dispatch of the march kernel carries {c}"
@@ -238,9 +254,10 @@ def main():
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("EXA_BENCH_IN_FLIGHT", "0")),
                     help="frames in flight: F > 1 renders consecutive frames with F renderer handles on F streams, so that "
                          "the tail of one frame (its longest rays) overlaps the bulk of the next; every frame is complete "
-                         "and gathered, frame k+F waits for frame k.  0 = default: 1 on one GPU (the GPU is full anyway, "
-                         "+1 %), 3 on a shard of several GPUs, where a rank's frame does not fill its GPU (rank 0 of 8 "
-                         "rehearsed: 4.6 -> 2.9 ms per frame)")
+                         "and gathered, frame k+F waits for frame k.  0 = default: 3 for every number of GPUs (one protocol "
+                         "for the whole scaling curve: on one GPU, which a frame fills anyway, it is worth about 1 %%; on a "
+                         "shard of 8 a rank's frame does not fill its GPU: 4.6 -> 2.9 ms per frame rehearsed); `latency_ms` "
+                         "in the line is one frame at a time")
     ap.add_argument("--spawn-check", action="store_true",
                     help="every rank prints its RANK/WORLD_SIZE/MASTER_* as one JSON line and exits (no GPU; tests)")
     args = ap.parse_args()
@@ -335,7 +352,7 @@ def main():
     rehearse = os.environ.get("EXA_BENCH_SHARD") if world == 1 else None
     shard_rank, shard_world = (int(x) for x in rehearse.split(",")) if rehearse else (rank, world)
 
-    F = args.in_flight if args.in_flight > 0 else (3 if shard_world > 1 else 1)
+    F = args.in_flight if args.in_flight > 0 else 3          # the same protocol for every N: `value` is a throughput
     basis_form = args.basis_form if args.basis_form >= 0 else binding.DEFAULT_BASIS_FORM
 
     def make_renderer():
@@ -560,6 +577,22 @@ def main():
         latency_ms = 1000.0 * float(el_l.item()) / n_lat
         R.setOption("wide_march", 0)
 
+    # the same frame with the basis sums in the reference's source order (option basis_form 0), lone synchronous frames: what
+    # the default association (a numerics change within the stated tolerance) buys is then separable in the line
+    kernel_ms_form0 = None
+    if basis_form == 1 and not os.environ.get("EXA_BENCH_NO_LATENCY"):
+        cur = torch.cuda.current_stream().cuda_stream
+        R.setOption("basis_form", 0)
+        R.updateFrameID(0)
+        ks = []
+        for i in range(4):
+            R.render(device_ptr=shards[0].data_ptr(), stream=cur)
+            if i:
+                ks.append(R.stats()["kernel_ms"])
+        kernel_ms_form0 = float(np.mean(ks)) * args.spp if args.spp == 1 else None
+        R.setOption("basis_form", 1)
+        R.render(device_ptr=shards[0].data_ptr(), stream=cur)          # shards[0] holds a frame of the default form again
+
     # aggregate per-rank work counters and kernel time
     agg = torch.tensor([st["samples"], st["brick_visits"], st["corner_loads"], st["segments"], st["nodes_visited"],
                         st["pixels"]], dtype=torch.float64, device=cdev)
@@ -618,6 +651,10 @@ def main():
                 "kernel": ("renderFrameKdKernel" if args.accel else "renderFrameKernel")
                           + (" + surfacePrepassKdKernel" if (args.iso is not None and args.accel) else ""),
                 "kernel_ms": k_ms,
+                **({"kernel_ms_basis_form0": kernel_ms_form0,
+                    "kernel_ms_basis_form0_note": "the same frame with option basis_form 0 (basis sums in the reference's source order, nothing "
+                                                  "fused), lone synchronous frames after the timed region: kernel_ms / this = what the default "
+                                                  "association contributes"} if kernel_ms_form0 is not None else {}),
                 "peak_note": "256 CUs x 4 SIMDs x 1 wave64 VALU instruction / 2 cycles at 2.4 GHz (MI355X_MICROARCH.md)",
                 "useful_flops_per_launch": flops,
                 "useful_flop_frac": flops / (k_ms * 1e-3) / (F32_VECTOR_PEAK_TFLOPS * 1e12),

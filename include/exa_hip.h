@@ -141,6 +141,9 @@ typedef struct ExaHipStats {
   uint64_t wave_iters;        /* kd march: march iterations of every wave's longest ray, summed over the waves ...       */
   uint64_t tile_iters;        /* ... and 4 x the slowest wave's per workgroup, summed: wave_iters / tile_iters = how evenly
                                  the four waves of a workgroup finish (its LDS is held until the slowest one does)        */
+  uint64_t walk_leaf_visits;  /* rope walk (option "walk"): leaves fetched, 64 B each — counted as four 16-byte nodes in
+                                 nodes_visited, so nodes_visited - 4 * walk_leaf_visits inner nodes were stepped through;
+                                 0 for the stack walk, whose leaves are references inside their parent node              */
 } ExaHipStats;
 
 typedef struct ExaHipRenderer ExaHipRenderer;
@@ -300,6 +303,13 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * size summed over the waves as walk_union_nodes (a diagnostic of how coherent the 64 walks of a wave are);
  * "profile_marker" N = launch an empty kernel (profileMarkerKernel) on the null stream now: a bracket in a profiler's
  * dispatch list, no effect on any frame.
+ * "walk" selects how the DVR march of the kd path finds its segments: 1 = the ordered walk of the region kd-tree with a
+ * 4-entry short stack in LDS (restart from the root when an entry was dropped), which skips subtrees without an active
+ * region; 2 = the rope walk: every leaf carries its box and one link per face to its neighbour (64 B per leaf, built on
+ * the host at the first frame that uses it), the ray goes from leaf to leaf, the reference's slab test is evaluated on
+ * each leaf's own box, no stack and no restarts — and the LDS of the stack goes to a segment queue of 8 instead of 4
+ * entries; inactive leaves are passed through one by one; 0 (default) = per frame: the rope walk when at least half of the
+ * regions are active for the volume march, else the stack walk.  Same segments, same pixels either way.
  * "basis_form" selects the association of the eight-corner sums of addBasisFunctions (programs/exabrick.cu:620-777):
  * 1 (default) = per axis — x-pairs, then y, then z, weight sums as products of per-axis sums — with fused multiply-adds
  * (49 instead of 116 floating-point operations per brick with derivatives), 0 = the reference's source order with every

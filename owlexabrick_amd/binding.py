@@ -72,7 +72,7 @@ class ExaHipStats(C.Structure):
                                           "iso_segments", "iso_evals", "nodes_visited", "node_bytes", "pixels")] + \
                [("diag", C.c_uint64 * 9), ("phase_cycles", C.c_uint64 * 5), ("kernel_ms", C.c_float), ("rebuild_ms", C.c_float),
                 ("walk_restarts", C.c_uint64), ("walk_union_nodes", C.c_uint64), ("walk_probe_overflow", C.c_uint64),
-                ("wave_iters", C.c_uint64), ("tile_iters", C.c_uint64)]
+                ("wave_iters", C.c_uint64), ("tile_iters", C.c_uint64), ("walk_leaf_visits", C.c_uint64)]
 
     def asdict(self):
         d = {}

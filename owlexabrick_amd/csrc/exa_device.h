@@ -71,6 +71,21 @@ struct alignas(16) KdNodeDev {
 };
 static_assert(sizeof(KdNodeDev) == 16, "kd node = one 16-byte load");
 
+// Leaf of the rope walk (64 B = four 16-byte loads), one per region plus one per gap (a child slot of the region kd-tree
+// that holds nothing: space no brick covers): its box, what the march needs from the region, whether it is active, and one
+// link per face to whatever lies across it — an inner node of ropeNodes (>= 0), a leaf (~index < 0), or EXA_KD_DONE
+// outside the root box.  The walk goes from leaf to leaf through these links: no stack, no restart from the root.
+struct alignas(16) RopeLeaf {
+  float    lo[3], hi0;      // domain lower, domain upper.x
+  float    hi1, hi2;        // domain upper.y, .z
+  uint32_t rec;             // the march tree's leaf reference: packed {listBegin | listSize-1 | level} (RenderArgs::leafBeginBits)
+  uint32_t flags;           // bit 0 active for the volume march, bit 1 active for the iso march (refreshed with the activity)
+  int32_t  rope[6];         // -x +x -y +y -z +z
+  int32_t  region;          // region id, -1 for a gap
+  int32_t  pad;
+};
+static_assert(sizeof(RopeLeaf) == 64, "rope leaf = four 16-byte loads");
+
 // region record of the kd path: exact domain for the slab test plus the march data (48 B)
 struct alignas(16) RegionRec {
   float   lo[3], hi0;       // domain lower, domain upper.x
@@ -99,6 +114,12 @@ struct DeviceScene {
 #ifndef EXA_KD_STACK_MULTI
 #define EXA_KD_STACK_MULTI 3   // the multi-channel march: one entry fewer, so that two TF tables + stack + queue fit 6 workgroups per CU
 #endif
+#ifndef EXA_ROPE_QUEUE
+#define EXA_ROPE_QUEUE 8    // segment queue of the rope walk: it keeps no stack, so the queue gets the stack's LDS as well (same 96 B per lane)
+#endif
+#ifndef EXA_ROPE_QUEUE_MULTI
+#define EXA_ROPE_QUEUE_MULTI 7   // ... with two TF tables in LDS (the multi-channel march): 84 B per lane keep six workgroups per CU
+#endif
 #ifndef EXA_SEG_QUEUE
 #define EXA_SEG_QUEUE 4     // ... and per-lane queue of accepted segments (12 B per entry): 96 B per lane = 6 workgroups per CU.
                             // Measured on C4 (stack/queue), bursts that end when no lane is dry: 4/4 22.42 ms, 3/5 22.56,
@@ -107,6 +128,7 @@ struct DeviceScene {
 // entries of the short stack in the LDS the 12-byte layout reserves (kKdStack / kKdStackMulti x 12 bytes per lane)
 enum { kKdStackEntries = EXA_KD_STACK, kKdStackMultiEntries = EXA_KD_STACK_MULTI };
 enum { kTile = 16, kTilePixels = 256, kStackDepth = 32, kKdStack = EXA_KD_STACK, kKdStackMulti = EXA_KD_STACK_MULTI, kSegQueue = EXA_SEG_QUEUE,
+       kRopeQueue = EXA_ROPE_QUEUE, kRopeQueueMulti = EXA_ROPE_QUEUE_MULTI,
        kKdBlock = 256,        // threads per workgroup of the kd kernel (measured on C4: 256 -> 38.1 ms, 128 -> 41.5, 64 -> 42.7)
        kWideSegCap = 256,
        kWalkProbeBits = 15, kWalkProbeSize = 1 << kWalkProbeBits };   // walk probe: entries of a wave's node set   // wide march: leaves a window walker lists per round (16 B each; a fuller window takes more rounds)
@@ -120,7 +142,9 @@ enum StatSlot { ST_SEGMENTS, ST_SAMPLE_EVALS, ST_SAMPLES, ST_BRICK_VISITS, ST_CO
                 // shader-clock cycles of the waves by phase (sum over waves): brick visit, sample epilogue, kd walk,
                 // segment pop, everything else (ray set-up, output)
                 ST_T_BRICK, ST_T_FINAL, ST_T_WALK, ST_T_SEG, ST_T_OTHER,
-                ST_RESTARTS, ST_UNION, ST_PROBE_OVERFLOW, ST_WAVE_ITERS, ST_TILE_ITERS, ST_COUNT };
+                ST_RESTARTS, ST_UNION, ST_PROBE_OVERFLOW, ST_WAVE_ITERS, ST_TILE_ITERS,
+                ST_ROPE_LEAVES,         // rope walk: leaves fetched (each counts as four 16-byte nodes in ST_NODES)
+                ST_COUNT };
 
 // a shaded surface hit whose ambient-occlusion rays aoRaysKdKernel traces: hit point + |cos| of the primary ray, normal +
 // ambient term, base colour + the LCG state its two samples draw from, pixel slot
@@ -137,6 +161,12 @@ struct RenderArgs {
   int32_t            kdMarchRoot;
   uint32_t           leafBeginBits, leafSizeBits;
   const RegionRec   *regionRec;
+  // rope walk of the DVR march (NULL: the stack walk): leaves with neighbour links + the tree to descend in behind a link
+  const RopeLeaf    *ropeLeaves;
+  const KdNodeDev   *ropeNodes;
+  int32_t            ropeRoot;
+  int32_t            ropeFastDiv;   // the scene's planes allow the short exact division (see ropeStep)
+  int32_t            ropeAddr32;    // ... and its leaf / node arrays are below 4 GiB
   int32_t            kdRoot;
   int32_t            kdIsoRoot;     // where the iso walk starts: kdRoot, or EXA_KD_EMPTY + 1 (= done) when the tree is one inactive leaf
   float              kdLo[3], kdHi[3];   // box of the kd root = union of all brick domains
@@ -204,6 +234,9 @@ hipError_t buildLbvhTopologyDevice(const float *boxes, uint32_t numPrims, BvhNod
   hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s);                     \
   hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf,                        \
                             int stats /*0, 1 counters, 2 phase times*/, hipStream_t s);                                 \
+  /* the same march on the rope walk (a.ropeLeaves) */                                                                  \
+  hipError_t launchRenderKdRope(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf,                    \
+                                int stats, hipStream_t s);                                                              \
   hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf,    \
                                 hipStream_t s);                                                                         \
   /* computeTraces (exabrick.cu:1531-1574): one thread per trace, run before the frame kernel */                        \
@@ -225,6 +258,8 @@ hipError_t launchRefit(BvhNode *nodes, const int32_t *nodeIds, int count, const 
                        const uint8_t *active, hipStream_t s);
 // kd activity bits of one height class; which = 0 volume, 1 iso
 hipError_t launchKdRefit(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count, const uint8_t *active, int which, hipStream_t s);
+// activity bit `which` of the rope leaves from the per-region flags; *activeCount += number of active regions (may be NULL)
+hipError_t launchRopeActivity(RopeLeaf *leaves, uint32_t numRegions, const uint8_t *active, int which, uint32_t *activeCount, hipStream_t s);
 // brick b's cells from srcBegin[b] to dstBegin[b] in every field (src -> dst), then `begin` of every brick record / march header
 hipError_t launchPermuteBricks(const float *src, float *dst, const uint32_t *srcBegin, const uint32_t *dstBegin, int4 *bricks,
                                unsigned long long numBricks, int4 *leafHdr, const int32_t *leafList, unsigned long long leafListSize,

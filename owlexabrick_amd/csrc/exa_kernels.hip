@@ -33,6 +33,11 @@
 // position org + t * dir, the cell coordinate (pos - lower) * 2^-level - 0.5, the gradient sumW * sumD - sumWV * sumDC, the
 // three dot products of the shading factor and the colour terms of the "over" operator
 #define EXA_F1 (EXA_BASIS_FORM == 1)
+// The march on the rope walk is compiled in translation units of its own (-DEXA_TU_ROPE=1: exa_kernels_f*r.o hold
+// launchRenderKdRope and nothing else), side by side with the others.
+#ifndef EXA_TU_ROPE
+#define EXA_TU_ROPE 0
+#endif
 namespace exa {
 namespace EXA_FORM_NS {
 
@@ -1453,6 +1458,7 @@ __global__ __launch_bounds__(256) void renderFrameKernel(const RenderArgs a)
   }
 }
 
+#if !EXA_TU_ROPE
 hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
@@ -1469,6 +1475,7 @@ hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso,
 #undef EXA_LAUNCH
   return hipGetLastError();
 }
+#endif // !EXA_TU_ROPE
 
 // ========================================================================
 // v2: region kd-tree walked front to back + flattened march.
@@ -1653,6 +1660,138 @@ __device__ __forceinline__ void kdStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin
   }
 }
 #undef EXA_KD_POP_LATER
+
+// ------------------------------------------------------------------------
+// Rope walk: the same ordered sequence of leaves without a stack.  Every leaf of the region kd-tree (and every empty
+// child slot, a "gap") carries its box and, per face, a link to what lies across it (RopeLeaf; built by the module).  At a
+// leaf the reference's slab test (exabrick.cu:197-210) is evaluated on the leaf's own box — the six (plane - o) / d the
+// intersection program computes for this region, so [t0, t1] need no argument about the path — and the walk leaves
+// through the face with the smallest exit distance.  A link may name an inner node (the neighbour across the face is
+// split further): the walk then descends by the stack walk's own rule — the far child when the plane's distance is
+// <= the distance at which the previous leaf was left, else the near child — so it reaches the leaf the stack walk
+// pops next.  Space skipping cannot prune subtrees here (an inactive leaf is visited and passed through); the module
+// uses this walk for frames in which most regions are active.
+//
+// The divisions: every quotient must be the correctly rounded (plane - o) / d.  With y = rcp(d) refined by one
+// Newton step, q = a * y followed by two fma corrections IS the instruction sequence of the hardware's IEEE division
+// (v_div_scale, v_rcp, 2 fma | mul, fma, fma, fma, v_div_fmas, v_div_fixup) minus its scaling and special-case steps;
+// those do nothing when 2^-30 <= |d| <= 2 and a is 0 or 2^-60 <= |a| <= 2^60, which the caller establishes per wave
+// (`fast`: direction and origin of every lane's ray, and the scene's planes, are in range); otherwise the plain division
+// is used.  The counting variant re-does every leaf with the plain division and counts mismatches.
+// ------------------------------------------------------------------------
+__device__ __forceinline__ float refinedRcp(float d)
+{
+  const float y = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(__builtin_fmaf(-d, y, 1.f), y, y);
+}
+__device__ __forceinline__ float divByRcp(float a, float d, float y)
+{
+  float q = a * y;
+  float r = __builtin_fmaf(-d, q, a);
+  q = __builtin_fmaf(r, y, q);
+  r = __builtin_fmaf(-d, q, a);
+  return __builtin_fmaf(r, y, q);
+}
+// is this ray's origin / direction in the range of the short division (see above; planes are checked by the module)
+__device__ __forceinline__ bool ropeRayInRange(const Ray &ray)
+{
+  bool ok = true;
+  const float dd[3] = { ray.dir.x, ray.dir.y, ray.dir.z }, oo[3] = { ray.org.x, ray.org.y, ray.org.z };
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const float ad = fabsf(dd[k]), ao = fabsf(oo[k]);
+    ok = ok && ad >= 9.31322574615478515625e-10f /* 2^-30 */ && ad <= 2.f
+            && (ao == 0.f || (ao >= 9.5367431640625e-07f /* 2^-20 */ && ao <= 1099511627776.f /* 2^40 */));
+  }
+  return ok;
+}
+
+// one step of the rope walk: the leaf stage (slab test, accept, leave through the exit face) and then, for a lane whose
+// link names an inner node, one level of the descent — so that a lane that has just taken a link also takes the next node
+// in the same call, as kdStep does.  QN: entries of the lane's segment queue.
+template <int STATS, bool SMALL, int QN>
+__device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a, int *qRegion, float *qT,
+                                         const Ray &ray, const V3 rcpDir, const bool fast)
+{
+  const float ox = ray.org.x, oy = ray.org.y, oz = ray.org.z, dx = ray.dir.x, dy = ray.dir.y, dz = ray.dir.z;
+  if (w.ref < 0 && w.ref != EXA_KD_DONE) {
+    C.phase(ST_W_LEAF);
+    C.count(ST_NODES, 4);
+    C.count(ST_ROPE_LEAVES);
+    const uint32_t leaf = (uint32_t)~w.ref;
+    const char *lp = SMALL ? reinterpret_cast<const char *>(a.ropeLeaves) + (leaf << 6)
+                           : reinterpret_cast<const char *>(a.ropeLeaves + leaf);
+    const float4 q0 = *reinterpret_cast<const float4 *>(lp), q1 = *reinterpret_cast<const float4 *>(lp + 16);
+    const int4 r2 = *reinterpret_cast<const int4 *>(lp + 32), r3 = *reinterpret_cast<const int4 *>(lp + 48);
+    // exabrick.cu:197-210 on this leaf's box (lo = q0.xyz, hi = q0.w, q1.xy)
+    float lx, hx, ly, hy, lz, hz;
+    if (fast) {
+      lx = divByRcp(q0.x - ox, dx, rcpDir.x); hx = divByRcp(q0.w - ox, dx, rcpDir.x);
+      ly = divByRcp(q0.y - oy, dy, rcpDir.y); hy = divByRcp(q1.x - oy, dy, rcpDir.y);
+      lz = divByRcp(q0.z - oz, dz, rcpDir.z); hz = divByRcp(q1.y - oz, dz, rcpDir.z);
+    } else {
+      lx = (q0.x - ox) / dx; hx = (q0.w - ox) / dx;
+      ly = (q0.y - oy) / dy; hy = (q1.x - oy) / dy;
+      lz = (q0.z - oz) / dz; hz = (q1.y - oz) / dz;
+    }
+    const float nx = fminf(lx, hx), ny = fminf(ly, hy), nz = fminf(lz, hz);
+    const float fx = fmaxf(lx, hx), fy = fmaxf(ly, hy), fz = fmaxf(lz, hz);
+    const float tOut = fminf(fminf(fx, fy), fz);                 // where the ray leaves the box (not clamped)
+    const float t0 = fmaxf(walkTmin, fmaxf(fmaxf(nx, ny), nz));
+    const float t1 = fminf(w.tEnd, tOut);                        // tEnd = min(ray.tmax, exit of the root box) >= every leaf's clamp
+    const bool active = (__float_as_uint(q1.w) & 1u) != 0u;
+    const bool hit = active && t0 < t1;
+    if (STATS == 1) {
+      // the plain slab test of the intersection program with the current ray.tmin (and the plain division)
+      Ray rr = ray; rr.tmin = walkTmin;
+      float s0, s1;
+      const bool shit = boxTest(rr, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), s0, s1);
+      if ((shit && active) != hit || (hit && (s0 != t0 || s1 != t1))) C.st[ST_KD_MISMATCH]++;
+    }
+    if (hit) {
+      const int qc = w.pk.get(PK_QCOUNT);
+      int slot = w.pk.get(PK_QHEAD) + qc;
+      slot = slot >= QN ? slot - QN : slot;
+      // what the march needs of the region: its packed record (the march tree's leaf reference), or the region id
+      qRegion[slot * kKdBlock] = a.leafBeginBits ? (int)__float_as_uint(q1.z) : r3.z;
+      qT[(2 * slot) * kKdBlock] = t0;
+      qT[(2 * slot + 1) * kKdBlock] = t1;
+      w.pk.inc(PK_QCOUNT);
+      walkTmin = t1 * (1.0000001f);                              // exabrick.cu:1698
+    }
+    // leave through the face with the smallest exit distance (the first axis in a tie: the leaf behind a face the ray
+    // only touches has an empty interval and is passed through)
+    const int linkX = dx > 0.f ? r2.y : r2.x, linkY = dy > 0.f ? r2.w : r2.z, linkZ = dz > 0.f ? r3.y : r3.x;
+    const int link = fx == tOut ? linkX : (fy == tOut ? linkY : linkZ);
+    w.tn = tOut;
+    w.ref = tOut < w.tEnd ? link : EXA_KD_DONE;                  // nothing behind tEnd can be hit (a NaN ray ends here as well)
+  }
+  if (w.ref >= 0) {
+    const int4 n = SMALL ? *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(a.ropeNodes) + ((uint32_t)w.ref << 4))
+                         : *reinterpret_cast<const int4 *>(a.ropeNodes + w.ref);
+    C.count(ST_NODES);
+    C.phase(ST_W_NODE);
+    C.probeNode(w.ref);
+    const float split = __int_as_float(n.x);
+    const int axis = n.y & 3;
+    float o = axis == 0 ? ox : oy, d = axis == 0 ? dx : dy;
+    o = axis == 2 ? oz : o;
+    d = axis == 2 ? dz : d;
+    bool goRight;                                                // right = upper side of the plane
+    if (fast) {
+      float y = axis == 0 ? rcpDir.x : rcpDir.y;
+      y = axis == 2 ? rcpDir.z : y;
+      const float ts = divByRcp(split - o, d, y);
+      goRight = (ts <= w.tn) == (d > 0.f);                       // far child when the plane lies at or before the entry distance
+    } else if (d == 0.f) {
+      goRight = !(o < split);                                    // parallel to the plane: the side that holds the origin
+    } else {
+      const float ts = (split - o) / d;
+      goRight = (ts <= w.tn) == (d > 0.f);
+    }
+    w.ref = goRight ? n.w : n.z;
+  }
+}
 
 // exabrick.cu:1408-1460 traceIsoRay on the kd walk (iso activity bits): segments come out of the
 // ordered walk, one lane at a time refills its own queue here (the iso pre-pass is not the
@@ -1966,6 +2105,7 @@ __device__ __forceinline__ uint32_t aoRayKey(const RenderArgs &a, uint32_t slot,
   }
   return cell * kAoDirClasses + oct * 3u + dom;
 }
+#if !EXA_TU_ROPE
 __global__ __launch_bounds__(256) void aoKeyKernel(const RenderArgs a)
 {
   const unsigned numRays = 2u * a.aoCount[0];
@@ -2018,6 +2158,8 @@ __global__ __launch_bounds__(256) void aoFinalizeKernel(const RenderArgs a)
     a.surf[slot] = make_float4(ngAmb.w + baseRnd.x * fd * ns, ngAmb.w + baseRnd.y * fd * ns, ngAmb.w + baseRnd.z * fd * ns, t_hit);
   }
 }
+
+#endif // !EXA_TU_ROPE
 
 // The ambient-occlusion rays of the hits surfacePrepassKdKernel<.., AO_DEFER> listed (exabrick.cu:1611-1652): lane 2h + i
 // traces sample i of hit h — the cosine-distributed direction from the hit's own LCG draws (:85-94, :1624-1633), the trace
@@ -2086,7 +2228,8 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_AO_ISO_WAVES : EXA_PREPAS
 // MULTI: 0 = one primary channel; 1 = several, at most two TF tables in LDS (the 6-workgroup layout below); 2 = several, more tables
 // NCH: 0 = cell values field by field (the ABI's layout; one channel, or the channels one after the other);
 //      2..4 = that many primary channels from the channel-interleaved copy, all of them per brick visit (addBasisFastIl)
-template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL, int NCH = 0>
+// ROPE: the walk is the rope walk (ropeStep) instead of the stack walk (kdStep); everything behind the segment queue is the same
+template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL, int NCH = 0, bool ROPE = false>
 __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL34_WAVES) : (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 5 : EXA_MARCH_WAVES)))) void renderFrameKdKernel(const RenderArgs a)
 {
   static_assert(NCH == 0 || (MULTI == 2 && STATS == 0), "the interleaved march is a multi-channel variant of the shipped kernel");
@@ -2096,13 +2239,16 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
   // way and the 80-VGPR build only costs (3 channels on C4: +2 %): MULTI == 2 keeps 4 entries and 5 waves per SIMD.
   constexpr int KSB = MULTI == 1 ? kKdStackMulti : kKdStack;                      // LDS: 12 bytes x KSB per lane for the stack
   constexpr int KS = MULTI == 1 ? kKdStackMultiEntries : kKdStackEntries;         // entries the walk keeps there
+  // entries of the lane's segment queue: the rope walk keeps no stack and gives the queue that LDS as well
+  constexpr int QN = ROPE ? (MULTI == 1 ? kRopeQueueMulti : kRopeQueue) : kSegQueue;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
   int *stackRef = reinterpret_cast<int *>(sp0);
   float *stackF = reinterpret_cast<float *>(sp0 + size_t(KS) * kKdBlock * 4) + threadIdx.x;
-  int *qRegion = reinterpret_cast<int *>(sp0 + size_t(KSB) * kKdBlock * 12) + threadIdx.x;
-  float *qT = reinterpret_cast<float *>(sp0 + size_t(KSB) * kKdBlock * 12 + size_t(kSegQueue) * kKdBlock * 4) + threadIdx.x;
+  unsigned char *q0 = ROPE ? sp0 : sp0 + size_t(KSB) * kKdBlock * 12;
+  int *qRegion = reinterpret_cast<int *>(q0) + threadIdx.x;
+  float *qT = reinterpret_cast<float *>(q0 + size_t(QN) * kKdBlock * 4) + threadIdx.x;
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
@@ -2185,7 +2331,15 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       w.tn = fmaxf(r0, ray.tmin);
       w.tf = fminf(r1, ray.tmax);
       w.tEnd = w.tf;
-      w.ref = (hit && w.tn < w.tf) ? a.kdMarchRoot : EXA_KD_DONE;
+      w.ref = (hit && w.tn < w.tf) ? (ROPE ? a.ropeRoot : a.kdMarchRoot) : EXA_KD_DONE;
+    }
+    // rope walk: refined reciprocals of the direction for the short exact division, valid when every ray of the wave
+    // (and the scene's planes) are in its range — one decision per wave, so the walk's code does not diverge on it
+    V3 rcpDir = mk(0.f, 0.f, 0.f);
+    bool ropeFast = false;
+    if (ROPE) {
+      ropeFast = a.ropeFastDiv != 0 && !anyLane(!ropeRayInRange(ray));
+      if (ropeFast) rcpDir = mk(refinedRcp(ray.dir.x), refinedRcp(ray.dir.y), refinedRcp(ray.dir.z));
     }
 
     float walkTmin = ray.tmin;
@@ -2228,12 +2382,13 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       // (starting a burst only once 2 / 4 / 8 lanes are dry, the dry ones sitting iterations out: 23.4 / 23.8 / 25.0 ms)
       if (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE)) {
         C.lap(ST_T_WALK);
-        __builtin_amdgcn_s_setprio(1);   // a burst is a chain of dependent node loads with every lane of the wave waiting
         do {
-          const bool want = w.pk.get(PK_QCOUNT) < kSegQueue && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
-          if (want) kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
+          const bool want = w.pk.get(PK_QCOUNT) < QN && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
+          if (want) {
+            if (ROPE) ropeStep<STATS, SMALL, QN>(C, w, walkTmin, a, qRegion, qT, ray, rcpDir, ropeFast);
+            else kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
+          }
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
-        __builtin_amdgcn_s_setprio(0);
       }
       if (!haveSeg) {
         // ---- next segment from this lane's queue ----
@@ -2244,7 +2399,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         const int region = qRegion[qh * kKdBlock];
         const float t0 = qT[(2 * qh) * kKdBlock];
         t1 = qT[(2 * qh + 1) * kKdBlock];
-        w.pk.template incWrap<kSegQueue>(PK_QHEAD);
+        w.pk.template incWrap<QN>(PK_QHEAD);
         w.pk.dec(PK_QCOUNT);
         if (a.leafBeginBits) {
           // the leaf reference of the march tree is the region's record itself: no load between the queue and
@@ -2297,7 +2452,6 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       if (child < listSize) continue;
 
       // ---- all bricks of the region seen: finish this channel's sample (:800-806, :910-927) ----
-      __builtin_amdgcn_s_setprio(1);
       C.lap(ST_T_FINAL);
       C.phase(ST_W_FINAL);
       if (NCH) {
@@ -2325,7 +2479,6 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0;
-      __builtin_amdgcn_s_setprio(0);
       if (MULTI && !NCH) {
         chan++;
         if (chan < numChannels) {
@@ -2769,6 +2922,7 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
 }
 
+#if !EXA_TU_ROPE
 hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s)
 {
   if (numTiles <= 0) return hipSuccess;
@@ -2829,8 +2983,11 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
   return hipGetLastError();
 }
 
+#endif // !EXA_TU_ROPE
+
 // the march over a.tileMap[0..numBlocks); `surf`: a surfaces pre-pass has filled a.surf / a.surfRnd
-hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats, hipStream_t s)
+template <bool ROPE>
+static hipError_t launchRenderKdT(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats, hipStream_t s)
 {
   if (numBlocks <= 0) return hipSuccess;
 #ifndef EXA_LDS_PAD
@@ -2841,12 +2998,14 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
   const int mode = a.p.numPrimaryChannels > 1 ? ((a.numXfChannels <= 2 && !stats) ? 1 : 2) : 0;
   // interleaved march: the module has built float[cell][numPrimaryChannels] (a.cellsIl); shipped kernel only
   const int nch = (!EXA_EMPTY_CELLS && a.cellsIl && !stats && a.p.numPrimaryChannels >= 2 && a.p.numPrimaryChannels <= 4) ? a.p.numPrimaryChannels : 0;
-  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4)
-                   + size_t((mode == 1 && !nch ? kKdStackMulti : kKdStack) + kSegQueue) * kKdBlock * 12 + EXA_LDS_PAD;
+  // per lane: stack + queue entries of 12 bytes (stack walk), or the queue alone (rope walk)
+  const size_t perLane = ROPE ? size_t(mode == 1 && !nch ? kRopeQueueMulti : kRopeQueue)
+                              : size_t((mode == 1 && !nch ? kKdStackMulti : kKdStack) + kSegQueue);
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + perLane * kKdBlock * 12 + EXA_LDS_PAD;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   // the instrumented variants keep the general address arithmetic (fewer instantiations)
-  const bool small = a.mul24 && a.addr32;
-#define EXA_LAUNCH(G, F, M, I, S, A) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S, A>), grid, block, lds, s, a)
+  const bool small = a.mul24 && a.addr32 && (!ROPE || a.ropeAddr32);
+#define EXA_LAUNCH(G, F, M, I, S, A) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S, A, 0, ROPE>), grid, block, lds, s, a)
 #define EXA_PICK2(G, F, M, I) do { if (stats == 1) EXA_LAUNCH(G, F, (M ? 2 : 0), I, 1, false); else if (stats == 2) EXA_LAUNCH(G, F, (M ? 2 : 0), I, 2, false); \
                                    else if (small) EXA_LAUNCH(G, F, M, I, 0, true); else EXA_LAUNCH(G, F, M, I, 0, false); } while (0)
 #define EXA_PICK(G, F, M) do { if (surf) EXA_PICK2(G, F, M, true); else EXA_PICK2(G, F, M, false); } while (0)
@@ -2855,7 +3014,7 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
   if (nch) {
     // LDS: nch TF tables + a 4-entry stack + the queue = 28 / 30 / 32 KB per workgroup (5 workgroups per CU)
     const bool smallIl = small && a.il32;
-#define EXA_IL4(G, F, I, A, N) hipLaunchKernelGGL((renderFrameKdKernel<G, F, 2, I, 0, A, N>), grid, block, lds, s, a)
+#define EXA_IL4(G, F, I, A, N) hipLaunchKernelGGL((renderFrameKdKernel<G, F, 2, I, 0, A, N, ROPE>), grid, block, lds, s, a)
 #define EXA_IL3(G, F, I, A) do { if (nch == 2) EXA_IL4(G, F, I, A, 2); else if (nch == 3) EXA_IL4(G, F, I, A, 3); else EXA_IL4(G, F, I, A, 4); } while (0)
 #define EXA_IL2(G, F, I) do { if (smallIl) EXA_IL3(G, F, I, true); else EXA_IL3(G, F, I, false); } while (0)
 #define EXA_IL1(G, F) do { if (surf) EXA_IL2(G, F, true); else EXA_IL2(G, F, false); } while (0)
@@ -2876,10 +3035,17 @@ hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fa
 #undef EXA_LAUNCH
   return hipGetLastError();
 }
+#if EXA_TU_ROPE
+hipError_t launchRenderKdRope(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats, hipStream_t s)
+{ return launchRenderKdT<true>(a, numBlocks, grad, fast, surf, stats, s); }
+#else
+hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf, int stats, hipStream_t s)
+{ return launchRenderKdT<false>(a, numBlocks, grad, fast, surf, stats, s); }
+#endif
 
 } // namespace EXA_FORM_NS
 
-#if EXA_BASIS_FORM == 0 && !EXA_EMPTY_CELLS     // kernels that never sample are compiled once
+#if EXA_BASIS_FORM == 0 && !EXA_EMPTY_CELLS && !EXA_TU_ROPE     // kernels that never sample are compiled once
 using namespace form0;
 // kd activity bits, one height class per launch (children before parents)
 __global__ __launch_bounds__(256) void kdRefitKernel(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t *nodeIds, int count,
@@ -2907,8 +3073,31 @@ hipError_t launchKdRefit(KdNodeDev *nodes, KdNodeDev *marchNodes, const int32_t 
   hipLaunchKernelGGL(kdRefitKernel, dim3((count + 255) / 256), dim3(256), 0, s, nodes, marchNodes, nodeIds, count, active, which);
   return hipGetLastError();
 }
+
+// activity bit of the rope leaves (the rope walk has no subtree bits to refit: every leaf carries its own flag), and the
+// number of active regions, from which the module decides which walk a frame takes
+__global__ __launch_bounds__(256) void ropeActivityKernel(RopeLeaf *leaves, uint32_t numRegions, const uint8_t *active, int which, uint32_t *activeCount)
+{
+  const uint32_t r = blockIdx.x * 256u + threadIdx.x;
+  const bool act = r < numRegions && active[r] != 0;
+  if (leaves && r < numRegions) {
+    const uint32_t f = leaves[r].flags;
+    leaves[r].flags = (f & ~(1u << which)) | ((act ? 1u : 0u) << which);
+  }
+  if (activeCount) {
+    const unsigned long long m = __ballot(act);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(activeCount, (uint32_t)__popcll(m));
+  }
+}
+hipError_t launchRopeActivity(RopeLeaf *leaves, uint32_t numRegions, const uint8_t *active, int which, uint32_t *activeCount, hipStream_t s)
+{
+  if (numRegions == 0) return hipSuccess;
+  hipLaunchKernelGGL(ropeActivityKernel, dim3((numRegions + 255) / 256), dim3(256), 0, s, leaves, numRegions, active, which, activeCount);
+  return hipGetLastError();
+}
 #endif
 
+#if !EXA_TU_ROPE
 namespace EXA_FORM_NS {
 
 // ------------------------------------------------------------------------
@@ -2976,8 +3165,9 @@ hipError_t launchComputeTraces(const RenderArgs &a, float *traces, int count, hi
 }
 
 } // namespace EXA_FORM_NS
+#endif // !EXA_TU_ROPE
 
-#if EXA_BASIS_FORM == 0 && !EXA_EMPTY_CELLS
+#if EXA_BASIS_FORM == 0 && !EXA_EMPTY_CELLS && !EXA_TU_ROPE
 // ------------------------------------------------------------------------
 // Region activity: the OPTIX_BOUNDS_PROGRAMs (exabrick.cu:250-312, 373-402)
 // ------------------------------------------------------------------------

@@ -12,7 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -271,6 +273,27 @@ struct ExaHipRenderer {
   bool haveKd = false;
   int accel = 1;                     // 1 = kd walk when available, 0 = LBVH
   float kdLo[3], kdHi[3];
+
+  // Rope walk of the DVR march (option "walk": 0 = chosen per frame, 1 = the stack walk, 2 = the rope walk).  The leaves of
+  // the kd-tree with their boxes and neighbour links are built on the host at the first frame that wants them (buildRopes);
+  // the stack walk skips inactive subtrees, the rope walk passes through every leaf on the ray, so the automatic choice
+  // takes the rope walk when at least kRopeActiveFraction of the regions are active for the volume march.
+  DevBuf<RopeLeaf> ropeLeaves;
+  DevBuf<KdNodeDev> ropeNodes;
+  DevBuf<uint32_t> activeCountBuf;
+  int32_t ropeRoot = EXA_KD_EMPTY + 1;
+  bool ropeBuilt = false, ropeFailed = false, ropeFlagsStale = true, ropeThisFrame = false;
+  int ropeFastDiv = 0, ropeAddr32 = 0;
+  int walkMode = 0;
+  uint32_t activeRegions = 0;        // regions active for the volume march (refreshed with the activity)
+  static constexpr double kRopeActiveFraction = 0.5;
+  bool ropeWanted() const
+  {
+    if (!useKd() || ropeFailed || walkMode == 1) return false;
+    if (walkMode == 2) return true;
+    return double(activeRegions) >= kRopeActiveFraction * double(sc.numRegions);
+  }
+  int buildRopes();
 
   // triangle surfaces
   DevBuf<BvhNode> meshNodes;
@@ -732,6 +755,7 @@ struct ExaHipRenderer {
     const bool needIso = isoEnabled();
     if (volDirty || (needIso && isoDirty)) {
       HIP_TRY(this, hipEventRecord(ev2, s));
+      const bool volChanged = volDirty;
       if (volDirty) {                       // needVolumeBVHRebuild (OptixRenderer.cpp:533-537)
         HIP_TRY(this, launchVolumeActivity(sc, fs, p, xf.p, volActive.p, tfFracMagic(), s));
         if (lbvhBuilt && refit(volNodes, volActive.p, s)) return 1;
@@ -748,9 +772,17 @@ struct ExaHipRenderer {
         if (haveKd && kdRefit(isoActive.p, 1, s)) return 1;
         isoDirty = false;
       }
+      if (haveKd && volChanged) {
+        // how many regions the volume march finds active: what the automatic choice of the walk looks at
+        if (!activeCountBuf.p) HIP_TRY(this, activeCountBuf.alloc(1));
+        HIP_TRY(this, hipMemsetAsync(activeCountBuf.p, 0, sizeof(uint32_t), s));
+        HIP_TRY(this, launchRopeActivity(ropeBuilt ? ropeLeaves.p : nullptr, sc.numRegions, volActive.p, 0, activeCountBuf.p, s));
+        ropeFlagsStale = !ropeBuilt;
+      }
       HIP_TRY(this, hipEventRecord(ev1, s));
       HIP_TRY(this, hipEventSynchronize(ev1));
       HIP_TRY(this, hipEventElapsedTime(&last.rebuild_ms, ev2, ev1));
+      if (haveKd && volChanged) HIP_TRY(this, hipMemcpy(&activeRegions, activeCountBuf.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
       if (haveKd && kdRoot < 0 && kdRoot != EXA_KD_EMPTY) {        // the kd tree is a single leaf: its activity lives here
         uint8_t f[2] = {1, 1};
         HIP_TRY(this, hipMemcpy(&f[0], volActive.p + ~kdRoot, 1, hipMemcpyDeviceToHost));
@@ -758,6 +790,17 @@ struct ExaHipRenderer {
         rootLeafVolActive = f[0] != 0;
         rootLeafIsoActive = f[1] != 0;
       }
+    }
+    // which walk this frame's DVR march takes
+    ropeThisFrame = ropeWanted();
+    if (ropeThisFrame && !ropeBuilt) {
+      HIP_TRY(this, hipStreamSynchronize(s));
+      if (buildRopes()) return 1;
+      ropeThisFrame = ropeBuilt;
+    }
+    if (ropeThisFrame && ropeFlagsStale) {
+      HIP_TRY(this, launchRopeActivity(ropeLeaves.p, sc.numRegions, volActive.p, 0, nullptr, s));
+      ropeFlagsStale = false;
     }
     return 0;
   }
@@ -878,6 +921,12 @@ struct ExaHipRenderer {
     a.leafBeginBits = packed ? leafBeginBits : 0;
     a.leafSizeBits = packed ? leafSizeBits : 0;
     a.regionRec = regionRec.p;
+    const bool rope = ropeThisFrame && ropeBuilt;
+    a.ropeLeaves = rope ? ropeLeaves.p : nullptr;
+    a.ropeNodes = ropeNodes.p;
+    a.ropeRoot = ropeRoot;
+    a.ropeFastDiv = ropeFastDiv;
+    a.ropeAddr32 = addr64 ? 0 : ropeAddr32;
     a.kdRoot = kdRoot;
     a.kdIsoRoot = rootLeafIsoActive ? kdRoot : EXA_KD_EMPTY + 1;
     for (int k = 0; k < 3; k++) { a.kdLo[k] = kdLo[k]; a.kdHi[k] = kdHi[k]; }
@@ -917,6 +966,11 @@ struct ExaHipRenderer {
       }
     }
     HIP_TRY(this, hipEventRecord(ev0, s));
+    // the one-lane DVR march on the walk chosen for this frame
+    auto march = [&](const RenderArgs &ra, int n, bool surfArg, int statsArg, hipStream_t st) -> hipError_t {
+      return rope ? EXA_FORM(launchRenderKdRope)(ra, n, p.gradientShadingDVR != 0, fastMath != 0, surfArg, statsArg, st)
+                  : EXA_FORM(launchRenderKd)(ra, n, p.gradientShadingDVR != 0, fastMath != 0, surfArg, statsArg, st);
+    };
     if (useKd()) {
       const bool surfOn = surfacesEnabled();
       const bool wide = !stats && !emptyCells && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
@@ -940,16 +994,16 @@ struct ExaHipRenderer {
         HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(ah, nPreHeavy, false, side2));
         HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
         HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(ac, nPreCheap, false, sideN));
-        HIP_TRY(this, EXA_FORM(launchRenderKd)(ac, nPreCheap, p.gradientShadingDVR != 0, fastMath != 0, true, 0, sideN));
+        HIP_TRY(this, march(ac, nPreCheap, true, 0, sideN));
         HIP_TRY(this, hipEventRecord(evJoinN, sideN));
-        HIP_TRY(this, EXA_FORM(launchRenderKd)(ah, nPreHeavy, p.gradientShadingDVR != 0, fastMath != 0, true, 0, side2));
+        HIP_TRY(this, march(ah, nPreHeavy, true, 0, side2));
         HIP_TRY(this, hipEventRecord(evJoin2, side2));
         HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
         HIP_TRY(this, hipStreamWaitEvent(s, evJoinN, 0));
       } else {
       if (surfOn) HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(a, numBlocks, stats, s));
       if (!wide) {
-        HIP_TRY(this, EXA_FORM(launchRenderKd)(a, numBlocks, p.gradientShadingDVR != 0, fastMath != 0, surfOn, stats ? statsMode : 0, s));
+        HIP_TRY(this, march(a, numBlocks, surfOn, stats ? statsMode : 0, s));
       } else {
         // the critical tiles on side streams so that they start together with the rest of the frame
         HIP_TRY(this, hipEventRecord(evFork, s));
@@ -973,7 +1027,7 @@ struct ExaHipRenderer {
         RenderArgs an = a;
         an.tileMap = normalMap.p;
         HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
-        HIP_TRY(this, EXA_FORM(launchRenderKd)(an, nNormal, p.gradientShadingDVR != 0, fastMath != 0, surfOn, false, sideN));
+        HIP_TRY(this, march(an, nNormal, surfOn, 0, sideN));
         HIP_TRY(this, hipEventRecord(evJoinN, sideN));
         if (nWide4) HIP_TRY(this, hipStreamWaitEvent(s, evJoin4, 0));
         if (nWide2) HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
@@ -987,6 +1041,149 @@ struct ExaHipRenderer {
     return 0;
   }
 };
+
+// Leaves and neighbour links of the rope walk, from the region kd-tree and the regions' domains as the device holds
+// them.  One top-down pass: a node hands each child its box and its six links (the child's sibling across the split
+// plane, the parent's links elsewhere), and every link is pushed down as far as it stays unambiguous — into the child
+// next to the face while the linked node splits along the face's axis, or into the one child whose side of a split the
+// whole face lies on (Popov et al. 2007, "Stackless kd-tree traversal").  Empty child slots of the tree (space no brick
+// covers) become gap leaves, so that a ray can pass through them.  The top levels are expanded serially, the subtrees
+// below them by a pool of threads.
+int ExaHipRenderer::buildRopes()
+{
+  const auto tBuild0 = std::chrono::steady_clock::now();
+  const size_t nk = kdNodes.n, nr = sc.numRegions;
+  std::vector<KdNodeDev> rn(nk);
+  std::vector<float> dom(6 * nr);
+  std::vector<RegionInfo> ri(nr);
+  if (nk) HIP_TRY(this, hipMemcpy(rn.data(), kdNodes.p, nk * sizeof(KdNodeDev), hipMemcpyDeviceToHost));
+  HIP_TRY(this, hipMemcpy(dom.data(), domain.p, dom.size() * sizeof(float), hipMemcpyDeviceToHost));
+  HIP_TRY(this, hipMemcpy(ri.data(), regionInfo.p, nr * sizeof(RegionInfo), hipMemcpyDeviceToHost));
+  // the tree the walk descends in: activity bits dropped, every empty child slot a gap leaf of its own
+  size_t gaps = 0;
+  for (KdNodeDev &n : rn) {
+    n.word &= 3u;
+    if (n.left == EXA_KD_EMPTY) n.left = ~int32_t(nr + gaps++);
+    if (n.right == EXA_KD_EMPTY) n.right = ~int32_t(nr + gaps++);
+  }
+  if (nr + gaps >= 0x7ffffff0ull) { ropeFailed = true; return 0; }
+  // the short exact division of the walk needs planes of moderate size on a binary grid (exa_kernels.hip: ropeStep)
+  bool planesOk = true;
+  for (float v : dom) planesOk = planesOk && std::isfinite(v) && std::fabs(v) <= 1073741824.f && v * 1024.f == std::nearbyint(v * 1024.f);
+  std::vector<RopeLeaf> leaves(nr + gaps);
+  struct Item { int32_t ref; float lo[3], hi[3]; int32_t rope[6]; };
+  std::atomic<bool> bad{false};
+  const uint32_t bb = leafBeginBits, sb = leafSizeBits;
+  auto emitLeaf = [&](const Item &it) {
+    const size_t id = size_t(~it.ref);
+    RopeLeaf &L = leaves[id];
+    L.lo[0] = it.lo[0]; L.lo[1] = it.lo[1]; L.lo[2] = it.lo[2];
+    L.hi0 = it.hi[0]; L.hi1 = it.hi[1]; L.hi2 = it.hi[2];
+    for (int f = 0; f < 6; f++) L.rope[f] = it.rope[f];
+    L.flags = 0; L.pad = 0;
+    if (id < nr) {
+      // the box the splits leave must be the region's domain, float for float: the slab test runs on it
+      for (int k = 0; k < 3; k++) if (dom[6 * id + k] != it.lo[k] || dom[6 * id + 3 + k] != it.hi[k]) bad = true;
+      L.region = (int32_t)id;
+      L.rec = (uint32_t)id;
+      if (bb) {
+        int lv = 0;
+        while (float(1 << lv) < ri[id].finestLevelCellWidth) lv++;
+        L.rec = uint32_t(ri[id].listBegin) | (uint32_t(ri[id].listSize - 1) << bb) | (uint32_t(lv) << (bb + sb));
+      }
+    } else {
+      L.region = -1; L.rec = 0;
+    }
+  };
+  // pushes the links of a box down (see above)
+  auto settle = [&](Item &it) {
+    for (int f = 0; f < 6; f++) {
+      const int fa = f >> 1;
+      const bool upper = (f & 1) != 0;
+      int32_t r = it.rope[f];
+      while (r >= 0) {
+        const KdNodeDev &n = rn[r];
+        const int ax = int(n.word);
+        if (ax == fa) r = upper ? n.left : n.right;              // the child that touches the face
+        else if (n.split >= it.hi[ax]) r = n.left;               // the face lies on the lower side of this split
+        else if (n.split <= it.lo[ax]) r = n.right;              // ... on the upper side
+        else break;
+      }
+      it.rope[f] = r;
+    }
+  };
+  // one node: its two children with their boxes and links
+  auto expand = [&](const Item &it, Item &L, Item &R) {
+    const KdNodeDev &n = rn[it.ref];
+    const int ax = int(n.word);
+    L = it; R = it;
+    L.ref = n.left; R.ref = n.right;
+    L.hi[ax] = n.split; R.lo[ax] = n.split;
+    L.rope[2 * ax + 1] = n.right;
+    R.rope[2 * ax] = n.left;
+    settle(L); settle(R);
+  };
+  auto subtree = [&](const Item &root) {
+    std::vector<Item> stack(1, root);
+    Item L, R;
+    while (!stack.empty()) {
+      const Item it = stack.back();
+      stack.pop_back();
+      if (it.ref < 0) { emitLeaf(it); continue; }
+      expand(it, L, R);
+      stack.push_back(L); stack.push_back(R);
+    }
+  };
+  Item root{};
+  root.ref = kdRoot;
+  for (int k = 0; k < 3; k++) { root.lo[k] = kdLo[k]; root.hi[k] = kdHi[k]; }
+  for (int f = 0; f < 6; f++) root.rope[f] = EXA_KD_EMPTY + 1;   // outside the root box: the walk is done
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const unsigned nthreads = nk < 4096 ? 1u : std::min(16u, hw);
+  std::vector<Item> frontier(1, root);
+  while (nthreads > 1 && frontier.size() < 64 * size_t(nthreads)) {
+    std::vector<Item> next;
+    bool any = false;
+    for (const Item &it : frontier) {
+      if (it.ref < 0) { next.push_back(it); continue; }
+      Item L, R;
+      expand(it, L, R);
+      next.push_back(L); next.push_back(R);
+      any = true;
+    }
+    frontier.swap(next);
+    if (!any) break;
+  }
+  std::atomic<size_t> cursor{0};
+  auto worker = [&] { for (size_t i; (i = cursor.fetch_add(1)) < frontier.size();) subtree(frontier[i]); };
+  if (nthreads > 1) {
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(worker);
+    for (auto &t : pool) t.join();
+  } else worker();
+  if (bad) {
+    // a tree whose planes do not reproduce the regions' domains (a caller's own kd-tree): the stack walk stays
+    if (std::getenv("EXA_HIP_VERBOSE")) std::fprintf(stderr, "[exa_hip] rope walk: the kd-tree's planes do not reproduce the region domains; stack walk kept\n");
+    ropeFailed = true;
+    return 0;
+  }
+  if (ropeLeaves.upload(leaves.data(), leaves.size()) != hipSuccess || ropeNodes.upload(rn.data(), rn.size()) != hipSuccess) {
+    // the links are an optimisation (64 B per leaf + 16 B per node of extra memory): without them the stack walk
+    (void)hipGetLastError();
+    ropeLeaves.release(); ropeNodes.release();
+    ropeFailed = true;
+    return 0;
+  }
+  ropeRoot = kdRoot;
+  ropeFastDiv = planesOk ? 1 : 0;
+  ropeAddr32 = (leaves.size() * sizeof(RopeLeaf) < (1ull << 32) && rn.size() * sizeof(KdNodeDev) < (1ull << 32)) ? 1 : 0;
+  ropeBuilt = true;
+  ropeFlagsStale = true;
+  if (std::getenv("EXA_HIP_VERBOSE"))
+    std::fprintf(stderr, "[exa_hip] rope walk: %zu leaves (%zu gaps), %zu nodes linked on %u threads in %.1f ms; short division %s\n", leaves.size(), gaps,
+                 rn.size(), nthreads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBuild0).count(), planesOk ? "on" : "off");
+  return 0;
+}
 
 extern "C" {
 
@@ -1582,6 +1779,10 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     return 0;
   }
   if (!std::strcmp(key, "accel")) { h->accel = value; return 0; }
+  if (!std::strcmp(key, "walk")) {
+    if (value < 0 || value > 2) { h->fail("exa_hip_set_option: walk is 0 (chosen per frame), 1 (stack walk) or 2 (rope walk)"); return 1; }
+    h->walkMode = value; return 0;
+  }
   if (!std::strcmp(key, "lbvh_build")) {              // 0 = on the device (default), 1 = on the host; before the first LBVH frame
     if (h->lbvhBuilt && value != h->lbvhOnHost) { h->fail("exa_hip_set_option: lbvh_build must be set before the LBVH is first used"); return 1; }
     h->lbvhOnHost = value; return 0;
@@ -1671,7 +1872,7 @@ static int renderMulti(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, 
       for (int i = 0; i < 9; i++) sum.diag[i] += k[ST_W_BRICK + i];
       for (int i = 0; i < 5; i++) sum.phase_cycles[i] += k[ST_T_BRICK + i];
       sum.walk_restarts += k[ST_RESTARTS]; sum.walk_union_nodes += k[ST_UNION]; sum.walk_probe_overflow += k[ST_PROBE_OVERFLOW];
-      sum.wave_iters += k[ST_WAVE_ITERS]; sum.tile_iters += k[ST_TILE_ITERS];
+      sum.wave_iters += k[ST_WAVE_ITERS]; sum.tile_iters += k[ST_TILE_ITERS]; sum.walk_leaf_visits += k[ST_ROPE_LEAVES];
     }
   }
   sum.pixels = uint64_t(h->W) * h->H;
@@ -1682,7 +1883,7 @@ static int renderMulti(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, 
     for (int i = 0; i < 9; i++) sum.diag[i] = keep.diag[i];
     for (int i = 0; i < 5; i++) sum.phase_cycles[i] = keep.phase_cycles[i];
     sum.walk_restarts = keep.walk_restarts; sum.walk_union_nodes = keep.walk_union_nodes; sum.walk_probe_overflow = keep.walk_probe_overflow;
-    sum.wave_iters = keep.wave_iters; sum.tile_iters = keep.tile_iters;
+    sum.wave_iters = keep.wave_iters; sum.tile_iters = keep.tile_iters; sum.walk_leaf_visits = keep.walk_leaf_visits;
   }
   h->last = sum;
   if (!dstIsDevice && rgba8) {
@@ -1725,7 +1926,7 @@ static int renderImpl(ExaHipRenderer *h, uint32_t *rgba8, int32_t dstIsDevice, h
     for (int i = 0; i < 9; i++) h->last.diag[i] = c[ST_W_BRICK + i];
     for (int i = 0; i < 5; i++) h->last.phase_cycles[i] = c[ST_T_BRICK + i];
     h->last.walk_restarts = c[ST_RESTARTS]; h->last.walk_union_nodes = c[ST_UNION]; h->last.walk_probe_overflow = c[ST_PROBE_OVERFLOW];
-    h->last.wave_iters = c[ST_WAVE_ITERS]; h->last.tile_iters = c[ST_TILE_ITERS];
+    h->last.wave_iters = c[ST_WAVE_ITERS]; h->last.tile_iters = c[ST_TILE_ITERS]; h->last.walk_leaf_visits = c[ST_ROPE_LEAVES];
     h->walkProbe.release();
   }
   h->last.pixels = px;

@@ -125,7 +125,11 @@ class Case:
         if self.meshes:
             R.setTriangles(*self._merged_meshes())
         if self.accel is not None:
-            R.setOption("accel", self.accel)
+            # 0 = LBVH restart per segment, 1 = region kd-tree with the stack walk, 2 = region kd-tree with the rope walk
+            # (None: the module's own choice per frame)
+            R.setOption("accel", 1 if self.accel else 0)
+            if self.accel:
+                R.setOption("walk", self.accel)
         if self.fast_math is not None:
             R.setOption("fast_math", self.fast_math)
         if self.tf_filter is not None:

@@ -85,7 +85,7 @@ CASES = {
 
 
 @pytest.mark.parametrize("form", [0, 1], ids=["source_order", "per_axis"])
-@pytest.mark.parametrize("accel", [1, 0], ids=["kd", "lbvh"])
+@pytest.mark.parametrize("accel", [1, 0, 2], ids=["kd", "lbvh", "rope"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_hip_matches_oracle(name, accel, form):
     """form: the association of the eight-corner basis sums, the same on both sides: the kernels execute
@@ -119,7 +119,7 @@ def test_shipped_kernel_equals_instrumented_variant(name, fast_math, form):
 
 
 @pytest.mark.parametrize("form", [0, 1], ids=["source_order", "per_axis"])
-@pytest.mark.parametrize("accel", [1, 0], ids=["kd", "lbvh"])
+@pytest.mark.parametrize("accel", [1, 0, 2], ids=["kd", "lbvh", "rope"])
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_shipped_defaults_within_stated_tolerance(name, accel, form):
     """every case of the matrix with the options a caller gets by default — fast_math=1 (hardware exp2/log2 opacity
