@@ -115,10 +115,11 @@ struct DeviceScene {
 #define EXA_KD_STACK_MULTI 3   // the multi-channel march: one entry fewer, so that two TF tables + stack + queue fit 6 workgroups per CU
 #endif
 #ifndef EXA_ROPE_QUEUE
-#define EXA_ROPE_QUEUE 8    // segment queue of the rope walk: it keeps no stack, so the queue gets the stack's LDS as well (same 96 B per lane)
+#define EXA_ROPE_QUEUE 6    // segment queue of the rope walk: it keeps no stack, so the queue gets the stack's LDS as well — six 16-byte
+                            // entries {region record, t1, first sample's t_i, t0} in the stack walk's 96 B per lane
 #endif
 #ifndef EXA_ROPE_QUEUE_MULTI
-#define EXA_ROPE_QUEUE_MULTI 7   // ... with two TF tables in LDS (the multi-channel march): 84 B per lane keep six workgroups per CU
+#define EXA_ROPE_QUEUE_MULTI 5   // ... with two TF tables in LDS (the multi-channel march): 80 B per lane keep six workgroups per CU
 #endif
 #ifndef EXA_SEG_QUEUE
 #define EXA_SEG_QUEUE 4     // ... and per-lane queue of accepted segments (12 B per entry): 96 B per lane = 6 workgroups per CU.

@@ -1709,9 +1709,11 @@ __device__ __forceinline__ bool ropeRayInRange(const Ray &ray)
 // one step of the rope walk: the leaf stage (slab test, accept, leave through the exit face) and then, for a lane whose
 // link names an inner node, one level of the descent — so that a lane that has just taken a link also takes the next node
 // in the same call, as kdStep does.  QN: entries of the lane's segment queue.
+// (The refined reciprocals are formed again at every step: kept in three registers across the march they cost the 80-register
+// kernel spills, and a step runs once per ~8 march iterations.)
 template <int STATS, bool SMALL, int QN>
-__device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a, int *qRegion, float *qT,
-                                         const Ray &ray, const V3 rcpDir, const bool fast)
+__device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a, float4 *queue,
+                                         const Ray &ray, const bool fast, const float samplingOffset)
 {
   const float ox = ray.org.x, oy = ray.org.y, oz = ray.org.z, dx = ray.dir.x, dy = ray.dir.y, dz = ray.dir.z;
   if (w.ref < 0 && w.ref != EXA_KD_DONE) {
@@ -1726,6 +1728,7 @@ __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTm
     // exabrick.cu:197-210 on this leaf's box (lo = q0.xyz, hi = q0.w, q1.xy)
     float lx, hx, ly, hy, lz, hz;
     if (fast) {
+      const V3 rcpDir = mk(refinedRcp(dx), refinedRcp(dy), refinedRcp(dz));
       lx = divByRcp(q0.x - ox, dx, rcpDir.x); hx = divByRcp(q0.w - ox, dx, rcpDir.x);
       ly = divByRcp(q0.y - oy, dy, rcpDir.y); hy = divByRcp(q1.x - oy, dy, rcpDir.y);
       lz = divByRcp(q0.z - oz, dz, rcpDir.z); hz = divByRcp(q1.y - oz, dz, rcpDir.z);
@@ -1752,10 +1755,18 @@ __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTm
       const int qc = w.pk.get(PK_QCOUNT);
       int slot = w.pk.get(PK_QHEAD) + qc;
       slot = slot >= QN ? slot - QN : slot;
-      // what the march needs of the region: its packed record (the march tree's leaf reference), or the region id
-      qRegion[slot * kKdBlock] = a.leafBeginBits ? (int)__float_as_uint(q1.z) : r3.z;
-      qT[(2 * slot) * kKdBlock] = t0;
-      qT[(2 * slot + 1) * kKdBlock] = t1;
+      // One 16-byte queue entry: what the march needs of the region — its packed record (the march tree's leaf reference),
+      // or the region id when the scene's records do not pack —, the segment [t0, t1], and the first sample's t_i
+      // (exabrick.cu:1141-1144), which is worked out HERE, where most lanes of the wave are busy, instead of at the pop,
+      // which runs in nearly every march iteration for a handful of lanes
+      float t_i = 0.f;
+      if (a.leafBeginBits) {
+        const uint32_t level = __float_as_uint(q1.z) >> (a.leafBeginBits + a.leafSizeBits);
+        const float flcw = __int_as_float((127 + (int)level) << 23);                       // 2^level
+        if (a.invDtPow2 != 0.f) t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float((127 - (int)level) << 23), samplingOffset);
+        else t_i = firstSampleT(t0, a.p.dt * flcw, samplingOffset);
+      }
+      queue[slot * kKdBlock] = make_float4(a.leafBeginBits ? q1.z : __int_as_float(r3.z), t1, t_i, t0);
       w.pk.inc(PK_QCOUNT);
       walkTmin = t1 * (1.0000001f);                              // exabrick.cu:1698
     }
@@ -1779,9 +1790,7 @@ __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTm
     d = axis == 2 ? dz : d;
     bool goRight;                                                // right = upper side of the plane
     if (fast) {
-      float y = axis == 0 ? rcpDir.x : rcpDir.y;
-      y = axis == 2 ? rcpDir.z : y;
-      const float ts = divByRcp(split - o, d, y);
+      const float ts = divByRcp(split - o, d, refinedRcp(d));
       goRight = (ts <= w.tn) == (d > 0.f);                       // far child when the plane lies at or before the entry distance
     } else if (d == 0.f) {
       goRight = !(o < split);                                    // parallel to the plane: the side that holds the origin
@@ -2249,6 +2258,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
   unsigned char *q0 = ROPE ? sp0 : sp0 + size_t(KSB) * kKdBlock * 12;
   int *qRegion = reinterpret_cast<int *>(q0) + threadIdx.x;
   float *qT = reinterpret_cast<float *>(q0 + size_t(QN) * kKdBlock * 4) + threadIdx.x;
+  float4 *queue4 = reinterpret_cast<float4 *>(sp0) + threadIdx.x;     // rope walk: 16-byte entries, one LDS access each
   for (int i = threadIdx.x; i < a.numXfChannels * EXA_NUM_XF_VALUES; i += kKdBlock) xfLds[i] = a.xf[i];
   __syncthreads();
 
@@ -2333,14 +2343,10 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       w.tEnd = w.tf;
       w.ref = (hit && w.tn < w.tf) ? (ROPE ? a.ropeRoot : a.kdMarchRoot) : EXA_KD_DONE;
     }
-    // rope walk: refined reciprocals of the direction for the short exact division, valid when every ray of the wave
-    // (and the scene's planes) are in its range — one decision per wave, so the walk's code does not diverge on it
-    V3 rcpDir = mk(0.f, 0.f, 0.f);
+    // rope walk: the short exact division is valid when every ray of the wave (and the scene's planes) are in its range —
+    // one decision per wave, so the walk's code does not diverge on it
     bool ropeFast = false;
-    if (ROPE) {
-      ropeFast = a.ropeFastDiv != 0 && !anyLane(!ropeRayInRange(ray));
-      if (ropeFast) rcpDir = mk(refinedRcp(ray.dir.x), refinedRcp(ray.dir.y), refinedRcp(ray.dir.z));
-    }
+    if (ROPE) ropeFast = a.ropeFastDiv != 0 && !anyLane(!ropeRayInRange(ray));
 
     float walkTmin = ray.tmin;
 
@@ -2385,7 +2391,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         do {
           const bool want = w.pk.get(PK_QCOUNT) < QN && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
           if (want) {
-            if (ROPE) ropeStep<STATS, SMALL, QN>(C, w, walkTmin, a, qRegion, qT, ray, rcpDir, ropeFast);
+            if (ROPE) ropeStep<STATS, SMALL, QN>(C, w, walkTmin, a, queue4, ray, ropeFast, interleavedSamplingOffset);
             else kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
           }
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
@@ -2396,9 +2402,16 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         const int qc = w.pk.get(PK_QCOUNT);
         if (qc == 0) break;                                                        // walk finished: ray done
         const int qh = w.pk.get(PK_QHEAD);
-        const int region = qRegion[qh * kKdBlock];
-        const float t0 = qT[(2 * qh) * kKdBlock];
-        t1 = qT[(2 * qh + 1) * kKdBlock];
+        int region;
+        float t0, tiQueued = 0.f;
+        if (ROPE) {
+          const float4 e = queue4[qh * kKdBlock];
+          region = __float_as_int(e.x); t1 = e.y; tiQueued = e.z; t0 = e.w;
+        } else {
+          region = qRegion[qh * kKdBlock];
+          t0 = qT[(2 * qh) * kKdBlock];
+          t1 = qT[(2 * qh + 1) * kKdBlock];
+        }
         w.pk.template incWrap<QN>(PK_QHEAD);
         w.pk.dec(PK_QCOUNT);
         if (a.leafBeginBits) {
@@ -2416,7 +2429,9 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         C.count(ST_SEGMENTS);
         haveSeg = true;
         w.pk.setBit(PK_NEEDHDR);
-        if (a.invDtPow2 != 0.f)                                   // :1141-1144
+        if (ROPE && a.leafBeginBits)                              // the walk has worked it out with the leaf (ropeStep)
+          t_i = tiQueued;
+        else if (a.invDtPow2 != 0.f)                              // :1141-1144
           t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float(0x7f000000 - __float_as_int(flcw)), interleavedSamplingOffset);
         else
           t_i = firstSampleT(t0, a.p.dt * flcw, interleavedSamplingOffset);
@@ -2436,6 +2451,8 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
       C.phase(ST_W_BRICK);
       // brick records are stored along the leaf list (no id indirection); a one-brick region keeps the
       // record it loaded at the start of the segment
+      // (requesting the NEXT visit's record here, behind this visit's cell loads — so that a visit in a region of several
+      // bricks does not wait for two loads one after the other — was measured: C4 17.35 -> 18.92 ms; profiles/r05_experiments.txt)
       if (listSize > 1 || w.pk.get(PK_NEEDHDR)) {
         if (SMALL) {                                       // the header array is below 4 GiB
           const char *hp = reinterpret_cast<const char *>(a.sc.leafHdr) + ((uint32_t)(listBegin + child) << 5);
@@ -2998,10 +3015,10 @@ static hipError_t launchRenderKdT(const RenderArgs &a, int numBlocks, bool grad,
   const int mode = a.p.numPrimaryChannels > 1 ? ((a.numXfChannels <= 2 && !stats) ? 1 : 2) : 0;
   // interleaved march: the module has built float[cell][numPrimaryChannels] (a.cellsIl); shipped kernel only
   const int nch = (!EXA_EMPTY_CELLS && a.cellsIl && !stats && a.p.numPrimaryChannels >= 2 && a.p.numPrimaryChannels <= 4) ? a.p.numPrimaryChannels : 0;
-  // per lane: stack + queue entries of 12 bytes (stack walk), or the queue alone (rope walk)
-  const size_t perLane = ROPE ? size_t(mode == 1 && !nch ? kRopeQueueMulti : kRopeQueue)
-                              : size_t((mode == 1 && !nch ? kKdStackMulti : kKdStack) + kSegQueue);
-  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + perLane * kKdBlock * 12 + EXA_LDS_PAD;
+  // per lane: stack + queue entries of 12 bytes (stack walk), or the queue alone in 16-byte entries (rope walk)
+  const size_t perLane = ROPE ? size_t(mode == 1 && !nch ? kRopeQueueMulti : kRopeQueue) * 16
+                              : size_t((mode == 1 && !nch ? kKdStackMulti : kKdStack) + kSegQueue) * 12;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + perLane * kKdBlock + EXA_LDS_PAD;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   // the instrumented variants keep the general address arithmetic (fewer instantiations)
   const bool small = a.mul24 && a.addr32 && (!ROPE || a.ropeAddr32);

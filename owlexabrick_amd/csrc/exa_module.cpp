@@ -792,7 +792,11 @@ struct ExaHipRenderer {
       }
     }
     // which walk this frame's DVR march takes
+    const bool ropeBefore = ropeThisFrame;
     ropeThisFrame = ropeWanted();
+    if (ropeThisFrame != ropeBefore && std::getenv("EXA_HIP_VERBOSE"))
+      std::fprintf(stderr, "[exa_hip] %u of %u regions active for the volume march: %s walk (option walk = %d)\n", activeRegions, sc.numRegions,
+                   ropeThisFrame ? "rope" : "stack", walkMode);
     if (ropeThisFrame && !ropeBuilt) {
       HIP_TRY(this, hipStreamSynchronize(s));
       if (buildRopes()) return 1;

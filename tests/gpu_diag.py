@@ -8,6 +8,8 @@ scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 sc = scenes.config("c4_exajet", scale=scale)
 case = Case(sc, W=2048, H=2048, grad=1, xf_domains=[(0.0, 1.0)])
 R = case.hip_renderer()
+if os.environ.get("EXA_DIAG_WALK"):                 # 1 = stack walk, 2 = rope walk (default: the module's choice)
+    R.setOption("walk", int(os.environ["EXA_DIAG_WALK"]))
 _, st = R.renderStats()
 d = st["diag"]
 names = ["brick", "final", "node", "leaf"]
@@ -16,6 +18,11 @@ for i, n in enumerate(names):
     w, l = d[2 * i], d[2 * i + 1]
     print(f"{n:6s} wave-execs {w:.4g} lanes {l:.4g} util {l / max(1, 64 * w):.3f}")
 print("kd mismatches", d[8])
+if st["walk_leaf_visits"]:
+    inner = st["nodes_visited"] - 4 * st["walk_leaf_visits"]
+    print(f"rope walk: {st['walk_leaf_visits']} leaves + {inner} inner nodes = {(st['walk_leaf_visits'] + inner) / st['segments']:.3f} visits per segment")
+else:
+    print(f"stack walk: {st['nodes_visited'] / st['segments']:.3f} node visits per segment, {st['walk_restarts']} restarts")
 R.setOption("stats_mode", 2)
 _, st2 = R.renderStats()
 R.setOption("stats_mode", 1)

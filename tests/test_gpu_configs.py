@@ -14,7 +14,7 @@ launch-order feedback and the wide march never change a pixel (also as rank 0 of
 import numpy as np
 import pytest
 
-from common import ACCUM_ATOL, ACCUM_RTOL, FLIP_BOUND, Case, po
+from common import ACCUM_ATOL, ACCUM_RTOL, FLIP_BOUND, FLIP_FRACTION, Case, po
 from owlexabrick_amd import harness, scenes
 
 pytestmark = pytest.mark.gpu
@@ -43,6 +43,13 @@ def _windows(acc, W, H, CROP=CROP):
             "silhouette": (best_sil[1], best_sil[2], best_sil[1] + CROP, best_sil[2] + CROP)}
 
 
+# An AO ray that flips hit / miss (cosf / sinf differ by ulps between libm and OCML) moves its frame's sample by half the
+# surface colour.  Observed on C5 (printed by the test; gpurun_out/r05_e_configs.log): 24 of 65 536 pixels of the dense 256^2
+# window after 16 accumulated frames (2.3e-5 per pixel and frame), 0 in the window across the silhouette, 41 of 1 048 576 in
+# the 1024^2 centre window of frame 0 (3.9e-5), termination flips included.  Allowed: three times the larger rate.
+AO_FLIP_FRACTION = 1.2e-4
+
+
 def _check_crop(acc_gpu, acc_cpu, win, frames, ao, what):
     x0, y0, x1, y1 = win
     g, o = acc_gpu[y0:y1, x0:x1].astype(np.float64), acc_cpu[y0:y1, x0:x1].astype(np.float64)
@@ -50,14 +57,14 @@ def _check_crop(acc_gpu, acc_cpu, win, frames, ao, what):
     tol = frames * ACCUM_ATOL + ACCUM_RTOL * np.abs(o)
     bad = int((d > tol).any(axis=-1).sum())
     n = d.shape[0] * d.shape[1]
+    print(f"{what}: {bad} of {n} pixels beyond {frames} x 2e-5 + 1e-4 |accum|, max |d accum| {d.max():.3g}")
+    assert o[..., :3].sum() > 0, what
     if ao:
-        # an AO ray that flips hit/miss (cosf/sinf ulps) moves its frame's sample by half the surface colour
-        assert bad <= max(5, int(0.004 * n * frames ** 0.5)), (what, bad, float(d.max()))
+        assert bad <= max(5, int(AO_FLIP_FRACTION * n * frames)), (what, bad, float(d.max()))
         return
     # termination flips only (tests/common.py): rare, and bounded by the transmittance left at 0.98
-    assert bad <= max(5, int(1e-3 * n * frames)), (what, bad, float(d.max()))
+    assert bad <= max(5, int(FLIP_FRACTION * n * frames)), (what, bad, float(d.max()))
     assert d.max() <= FLIP_BOUND * frames, (what, float(d.max()))
-    assert o[..., :3].sum() > 0, what
 
 
 class Config:
@@ -82,11 +89,15 @@ class Config:
             rgba = self.R.render()
         return rgba, self.R.readAccum()
 
-    def oracle_frames(self, win, frames=1, nthreads=16):
+    def oracle_frames(self, win, frames=1, nthreads=16, basis_form=None):
         S, acc = self.oracle(), None
+        if basis_form is not None:
+            S.set_basis_form(basis_form)
         for f in range(frames):
             fs, P = self.case.oracle_state(S, frameID=f)
             _, acc, st = S.render(fs, P, self.case.W, self.case.H, window=win, accum=acc, nthreads=nthreads)
+        if basis_form is not None:
+            S.set_basis_form(self.case.basis_form)
         return acc
 
     def close(self):
@@ -111,6 +122,11 @@ def _properties(cfg, frames=1, lbvh=True):
         R.setOption("accel", 1)
         R.setOption("fast_math", 1)
         assert _same(kd0, lb0)
+    # ---- the stack walk and the rope walk of the kd path find the same segments: bit-equal frames ----
+    for walk in (1, 2):
+        R.setOption("walk", walk)
+        assert _same(cfg.render_frames(frames), base), f"walk {walk}"
+    R.setOption("walk", 0)
     # ---- launch order / feedback / wide march never change a pixel ----
     for order in (0, 5):
         R.setOption("tile_order", order)
@@ -157,11 +173,56 @@ def _oracle_whole_frame(cfg, base_acc, what):
           f"{int((np.abs(base_acc.astype(np.float64) - acc) > ACCUM_ATOL + ACCUM_RTOL * np.abs(acc)).any(axis=-1).sum())} of {W * H}")
 
 
+# Form 1 (the shipped default: basis sums per axis with fused multiply-adds) against form 0 (the reference's source order),
+# stated in DESIGN.md 2: |d accum| <= 1e-3 (except for rays whose termination moves by one sample: <= 0.021, at most 0.05 % of
+# the pixels), RGBA8 <= 1 LSB, at most 1 % of the pixels beyond the CPU-vs-GPU tolerance.  Each form is tied to the oracle in the same form bit-tightly elsewhere; this is the one comparison that tells
+# what the default changes in the picture, on the whole frame at BASELINE size.
+FORM_ACCUM_BOUND = 1e-3
+FORM_PIXEL_FRACTION = 0.01
+
+
+def _form1_vs_form0(cfg, what, oracle_form0=False):
+    from owlexabrick_amd import harness as hs
+    R = cfg.R
+    R.setOption("basis_form", 1)
+    rgba1, acc1 = cfg.render_frames(1)
+    R.setOption("basis_form", 0)
+    rgba0, acc0 = cfg.render_frames(1)
+    R.setOption("basis_form", cfg.case.basis_form)
+    d = np.abs(acc1.astype(np.float64) - acc0.astype(np.float64))
+    moved = int((d > ACCUM_ATOL + ACCUM_RTOL * np.abs(acc0)).any(axis=-1).sum())
+    lsb = int(np.abs(hs.unpack_rgba8(rgba1).astype(np.int32) - hs.unpack_rgba8(rgba0).astype(np.int32)).max())
+    n = acc0.shape[0] * acc0.shape[1]
+    flips = int((d > FORM_ACCUM_BOUND).any(axis=-1).sum())
+    print(f"{what}: GPU form 1 vs GPU form 0, whole frame: max |d accum| {d.max():.3g}, {moved} of {n} pixels ({100.0 * moved / n:.3f} %) "
+          f"beyond 2e-5 + 1e-4 |accum|, {flips} beyond 1e-3 (a ray that ends one sample earlier or later), RGBA8 max {lsb} LSB")
+    # the association moves a pixel by at most 1e-3 — unless it moves the 0.98 termination decision of its ray by one sample,
+    # which is worth up to 0.021 and allowed for the same fraction of pixels as between CPU and GPU (tests/common.py)
+    assert lsb <= 1 and moved <= FORM_PIXEL_FRACTION * n, (what, lsb, moved)
+    assert flips <= max(5, int(FLIP_FRACTION * n)) and d.max() <= FORM_ACCUM_BOUND + FLIP_BOUND, (what, flips, float(d.max()))
+    if oracle_form0:
+        # ... and the default GPU frame against the form-0 ORACLE itself (the definition), same bounds
+        import time
+        t = time.time()
+        W, H = cfg.case.W, cfg.case.H
+        o0 = cfg.oracle_frames((0, 0, W, H), basis_form=0).astype(np.float64)
+        do = np.abs(acc1.astype(np.float64) - o0)
+        moved_o = int((do > ACCUM_ATOL + ACCUM_RTOL * np.abs(o0)).any(axis=-1).sum())
+        print(f"{what}: GPU form 1 (default) vs ORACLE form 0 (source order), whole frame: max |d accum| {do.max():.3g}, {moved_o} of {n} "
+              f"pixels ({100.0 * moved_o / n:.3f} %) beyond 2e-5 + 1e-4 |accum| (oracle {time.time() - t:.1f}s)")
+        # a termination flip (<= 0.021) may sit on top of the association's own difference
+        assert do.max() <= FORM_ACCUM_BOUND + FLIP_BOUND and moved_o <= FORM_PIXEL_FRACTION * n, (what, float(do.max()), moved_o)
+        assert int((do > FORM_ACCUM_BOUND).any(axis=-1).sum()) <= max(5, int(FLIP_FRACTION * n)), what
+        # GPU form 0 against the form-0 oracle: the tight tolerance (termination flips only)
+        _check_crop(acc0, o0, (0, 0, W, H), 1, 0, f"{what} GPU form 0 vs oracle form 0, whole frame")
+
+
 def test_c2_lanl_1024_dvr():
     cfg = Config("c2_lanl", 1024)
     try:
         base = _properties(cfg)
         _oracle_whole_frame(cfg, base[1], "C2")
+        _form1_vs_form0(cfg, "C2", oracle_form0=True)
     finally:
         cfg.close()
 
@@ -172,6 +233,7 @@ def test_c3_gear_2048_dvr_two_channels_plus_iso():
         assert cfg.R.params.numPrimaryChannels == 2
         base = _properties(cfg)
         _oracle_whole_frame(cfg, base[1], "C3")
+        _form1_vs_form0(cfg, "C3 (DVR of two channels + iso-surface)")
     finally:
         cfg.close()
 
@@ -210,6 +272,7 @@ def test_c4_exajet_full_2048_dvr(exajet_full):
     assert cfg.sc.num_cells > 6e8
     base = _properties(cfg)
     _oracle_whole_frame(cfg, base[1], "C4")
+    _form1_vs_form0(cfg, "C4", oracle_form0=True)
 
 
 def test_c5_exajet_full_4096_dvr_iso_ao_16_frames(exajet_full):
@@ -221,6 +284,10 @@ def test_c5_exajet_full_4096_dvr_iso_ao_16_frames(exajet_full):
     cfg.R.setOption("wide_march", 1)
     base = cfg.render_frames(16)
     _oracle_crops(cfg, base[1], frames=16, ao=1, what="C5", crop=256)      # two 256 x 256 windows x 16 accumulated frames
+    # ... and the 1024 x 1024 centre window of frame 0 (a sixteenth of the 4096^2 frame; ~15 s of oracle time)
+    first = cfg.render_frames(1)
+    win = (1536, 1536, 2560, 2560)
+    _check_crop(first[1], cfg.oracle_frames(win, 1), win, 1, 1, "C5 frame 0, 1024^2 centre window")
     # the iso-surface is really marched (the DVR in front of it leaves little of it visible with the default TF)
     cfg.R.updateFrameID(0)
     _, st = cfg.R.renderStats()

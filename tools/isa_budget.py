@@ -47,7 +47,7 @@ def phase_of(line):
         return "brick visit"
     if f in ("lookupXF", "shadeSample", "compositeSample", "integrateVolume", "fdiv", "fsqrt", "dotF", "gradOf"):
         return "sample epilogue"
-    if f in ("kdStep", "kdPop"):
+    if f in ("kdStep", "kdPop", "ropeStep", "refinedRcp", "divByRcp", "ropeRayInRange"):
         return "kd walk"
     if f in ("firstSampleT", "firstSampleTPow2"):
         return "segment pop"
@@ -136,7 +136,7 @@ for l in lines[start:end]:
         # dot, normalize, fdiv, fsqrt: lines < 62 except the LCG) are inlined everywhere: both stay with the phase
         # of the instruction before them
         ln_ = int(m.group(2))
-        helper = ln_ < 62 and not (36 <= ln_ <= 55)
+        helper = ln_ < 70 and not (40 <= ln_ <= 62)
         if int(m.group(1)) == 0 and ln_ > 0 and not helper:
             cur_line = (0, ln_)
         continue

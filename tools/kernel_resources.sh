@@ -1,5 +1,6 @@
 #!/bin/bash
-# Registers / scratch / LDS of the kernels in csrc/exa_kernels_f0.o (EXA_FORM=1: _f1.o; gfx950 code object), optionally filtered by a regex.
+# Registers / scratch / LDS of the kernels in csrc/exa_kernels_f0.o (EXA_FORM=1: _f1.o, EXA_FORM=1r: the rope march of form 1, ...;
+# gfx950 code object), optionally filtered by a regex.
 # usage: tools/kernel_resources.sh [regex]   (run after `make -C owlexabrick_amd/csrc`)
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
