@@ -183,14 +183,36 @@ def live_pmc(child_args, seconds=300.0, extra_env=None, frames=None):
                    sys.executable, os.path.abspath(__file__), *child_args]
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
                                  start_new_session=True)
+            # A counter request the hardware cannot serve is refused by the profiler's tool library at the first dispatch
+            # ("Could not construct profile cfg ... error code 38"); the library then aborts the child and hangs in its own
+            # finalisation (recorded in round 4: gpurun_out/r04_e_ta/pass0.log — blocked in the profiler, not in bench.py),
+            # so the child would sit there until the time limit.  Watch its stderr and end it at once instead.
+            err_lines, refused = [], []
+
+            def watch():
+                for raw in iter(p.stderr.readline, b""):
+                    line = raw.decode(errors="replace").rstrip()
+                    err_lines.append(line)
+                    if "Could not construct profile cfg" in line or "rocprofv3 caught signal" in line:
+                        refused.append(line)
+                        try:
+                            os.killpg(p.pid, signal.SIGKILL)             # the process group this call created
+                        except ProcessLookupError:
+                            pass
+                        return
+            watcher = threading.Thread(target=watch, daemon=True)
+            watcher.start()
             try:
-                _, err = p.communicate(timeout=seconds)
+                p.wait(timeout=seconds)
             except subprocess.TimeoutExpired:
-                os.killpg(p.pid, signal.SIGKILL)                     # the process group this call created
+                os.killpg(p.pid, signal.SIGKILL)
                 p.wait()
                 return None, f"pass {i} ({' '.join(counters)}) exceeded {seconds:.0f}s"
+            watcher.join(timeout=5.0)
+            if refused:
+                return None, f"pass {i} ({' '.join(counters)}) refused by the profiler: {refused[0][:200]}"
             if p.returncode != 0:
-                tail = (err or b"").decode(errors="replace").strip().splitlines()[-1:] or [""]
+                tail = err_lines[-1:] or [""]
                 return None, f"pass {i} ({' '.join(counters)}) exited with {p.returncode}: {tail[0][:200]}"
             csvs = glob.glob(os.path.join(out_dir, f"pass{i}", "**", "*counter_collection.csv"), recursive=True)
             if os.environ.get("EXA_BENCH_KEEP_PMC_CSV"):             # keep the raw lists (tests/golden fixtures, debugging)

@@ -103,7 +103,8 @@ typedef struct ExaHipScene {
   const ExaKdNode      *kdNodes;       /* optional (may be NULL) */
   uint64_t              numKdNodes;
   int32_t               kdRoot;        /* reference of the root (a leaf ref for a one-region scene) */
-  /* (added in round 4, at the end: a caller that fills the struct by hand zero-initialises it first) */
+  /* (added in round 4, at the end: a caller that fills the struct by hand zero-initialises it first; exa_hip_create refuses
+     any value other than 0 and 1, so that a struct filled field by field without this one is caught, not misread) */
   int32_t               allowEmptyCells; /* the reference's compile-time option ALLOW_EMPTY_CELLS (CMakeLists.txt:70-73, default
                                           OFF) as a property of the scene: scalars equal to EXA_EMPTY_CELL_POISON_VALUE are
                                           "no cell here" and addBasisFunctions skips them (programs/exabrick.cu:614-618) */
@@ -112,7 +113,7 @@ typedef struct ExaHipScene {
 /* programs/FrameState.h:27 */
 #define EXA_EMPTY_CELL_POISON_VALUE (-1e20f)
 /* exa_prep_create_ex flags */
-#define EXA_PREP_ALLOW_EMPTY_CELLS 1   /* cell id -1 = no cell: its slot holds the poison value (exa/OptixRenderer.cpp:116-118) */
+#define EXA_PREP_ALLOW_EMPTY_CELLS 1   /* a negative cell id = no cell: its slot holds the poison value (exa/OptixRenderer.cpp:116-118) */
 
 /* work counters of one frame (instrumented kernel variant); the basis of the
  * algorithmic-bytes figure in DESIGN.md */
@@ -166,7 +167,8 @@ int exa_prep_create(const int32_t *bricks7, uint64_t numBricks,
                     int32_t numFields, int32_t numRegionFields, int32_t numThreads,
                     ExaPrep **out);
 /* as exa_prep_create with `flags` (EXA_PREP_*).  EXA_PREP_ALLOW_EMPTY_CELLS = the reference built with
- * -DALLOW_EMPTY_CELLS=1: negative cell ids other than -1 stay an error; the regions' value ranges include the poison
+ * -DALLOW_EMPTY_CELLS=1: every negative cell id is "no cell", as in the renderer (exa/OptixRenderer.cpp:116-118; that only -1
+ * occurs is an assert of the loader, exa/ExaBricks.cpp:46-49, compiled out of a release build); the regions' value ranges include the poison
  * value, as the reference's computeValueRange (exa/Regions.cpp:182-240) does; the scene is marked allowEmptyCells */
 int exa_prep_create_ex(const int32_t *bricks7, uint64_t numBricks,
                        const int32_t *cellIDs, uint64_t numCellIDs,
@@ -297,7 +299,10 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * throughput), 0 = the whole pre-pass in front of the whole march; "ao_defer" 1 (default) = the ambient-occlusion rays of the shaded hits are traced by a launch of their own,
  * one ray per lane over a compact list of the hits, 2 = as 1 with the listed rays sorted on the device by (32x32-pixel block of the
  * hit | direction class: octant x dominant axis) before they are traced, so that a wave's 64 rays start close together and head
- * the same way (counting sort: histogram, scan, scatter; hit flags combined per hit by a last kernel), 0 = inline behind each pixel's primary ray (1 is the default); "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
+ * the same way (counting sort: histogram, scan, scatter; hit flags combined per hit by a last kernel), 0 = inline behind each pixel's primary ray (1 is the default); "ao_overlap" 1 (default) = the deferred AO rays run on a side
+ * stream BESIDE the march instead of in front of it: the march needs the surfaces' hit distance up front but their colour only for
+ * its last operation, so it stores its pixel colour and a small kernel finishes the pixels (over the surfaces' colour, accumulation,
+ * sRGB, pack: the same operations in the same order) once both are done, 0 = pre-pass, AO rays, march one after the other; "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
  * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change; "walk_probe" 1 = the
  * counting variant also records every wave's SET of visited kd nodes (128 KiB of device memory per wave) and reports its
  * size summed over the waves as walk_union_nodes (a diagnostic of how coherent the 64 walks of a wave are);

@@ -202,6 +202,7 @@ struct RenderArgs {
                                     // a peer-mapped pointer to the root device's buffer); accum / surf stay tile-major
   float4            *accum;
   float4            *surf;          // surfaces pre-pass -> march: {background rgb, surface t_hit} per pixel slot
+  float4            *pixOut;        // != null: the march stores its pixel colour here instead of finishing the pixel (compositeKdKernel does)
   uint32_t          *surfRnd;       // LCG state after the pre-pass' draws
   unsigned long long *stats;        // ST_COUNT counters (instrumented variant)
   int32_t           *errorFlag;     // set when a loop guard trips
@@ -233,6 +234,9 @@ hipError_t buildLbvhTopologyDevice(const float *boxes, uint32_t numPrims, BvhNod
 #define EXA_FORM_LAUNCHERS                                                                                              \
   hipError_t launchRender(const RenderArgs &a, int numBlocks, bool grad, bool iso, bool stats, hipStream_t s);          \
   hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats, hipStream_t s);                     \
+  /* the deferred AO rays of that pre-pass' hits; the finish of the pixels of a march that stored its colour (pixOut) */ \
+  hipError_t launchAoRaysKd(const RenderArgs &a, int numBlocks, hipStream_t s);                                         \
+  hipError_t launchCompositeKd(const RenderArgs &a, int numBlocks, hipStream_t s);                                      \
   hipError_t launchRenderKd(const RenderArgs &a, int numBlocks, bool grad, bool fast, bool surf,                        \
                             int stats /*0, 1 counters, 2 phase times*/, hipStream_t s);                                 \
   /* the same march on the rope walk (a.ropeLeaves) */                                                                  \

@@ -2542,6 +2542,11 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
                             : size_t(tile / a.world) * kTilePixels + (inY2 * kTile + inX2);
       colorSlot = a.colorRowMajor ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2) : slot;
     }
+    if (SURF && a.pixOut) {
+      // The surfaces' colour may still be in the making — the ambient-occlusion rays run BESIDE this march (exa_module:
+      // ao_overlap) —, so the pixel is finished by compositeKdKernel once both are done: same operations, same order.
+      a.pixOut[slot] = make_float4(pixelColor.x, pixelColor.y, pixelColor.z, pixelColor.w);
+    } else {
     float4 bgColor = make_float4(0.f, 0.f, 0.f, 0.f);
     if (SURF) bgColor = a.surf[slot];
     float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
@@ -2556,6 +2561,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
     const float div = frameID + 1.f;
     cr = cr / div; cg = cg / div; cb = cb / div;
     a.color[colorSlot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+    }
   }
 
   if (a.tileCost) {
@@ -2940,6 +2946,40 @@ __global__ __launch_bounds__(kKdBlock, 4) void renderFrameKdWideKernel(const Ren
 }
 
 #if !EXA_TU_ROPE
+// The end of renderFrame (exabrick.cu:1701-1719) for a march that stored its pixel colour instead of finishing the pixel
+// (RenderArgs::pixOut): colour over the surfaces' colour, accumulation, sRGB, pack — the operations of the march kernel's own
+// epilogue, in its order, one thread per pixel of the launched tiles.
+__global__ __launch_bounds__(256) void compositeKdKernel(const RenderArgs a)
+{
+  const int tile = a.tileMap[blockIdx.x];
+  const int tx = tile % a.tilesX, ty = tile / a.tilesX;
+  const int inX = threadIdx.x & 15, inY = threadIdx.x >> 4;
+  const int px = tx * kTile + inX, py = ty * kTile + inY;
+  if (!(px < a.W && py < a.H) || !(a.debugPixel < 0 || a.debugPixel == px + a.W * py)) return;
+  const size_t slot = (a.world == 1) ? size_t(px) + size_t(a.W) * py : size_t(tile / a.world) * kTilePixels + (inY * kTile + inX);
+  const size_t colorSlot = a.colorRowMajor ? size_t(px) + size_t(a.W) * py : slot;
+  const float4 pixelColor = a.pixOut[slot];
+  const float4 bgColor = a.surf[slot];
+  const int frameID = a.fs.frameID;
+  float cr = pixelColor.w * pixelColor.x + (1.f - pixelColor.w) * bgColor.x;     // :1701
+  float cg = pixelColor.w * pixelColor.y + (1.f - pixelColor.w) * bgColor.y;
+  float cb = pixelColor.w * pixelColor.z + (1.f - pixelColor.w) * bgColor.z;
+  if (frameID > 0) {
+    const float4 acc = a.accum[slot];
+    cr += acc.x; cg += acc.y; cb += acc.z;
+  }
+  a.accum[slot] = make_float4(cr, cg, cb, 1.f);
+  const float div = frameID + 1.f;
+  cr = cr / div; cg = cg / div; cb = cb / div;
+  a.color[colorSlot] = make_rgba8(linear_to_srgb(cr), linear_to_srgb(cg), linear_to_srgb(cb));
+}
+hipError_t launchCompositeKd(const RenderArgs &a, int numBlocks, hipStream_t s)
+{
+  if (numBlocks <= 0) return hipSuccess;
+  hipLaunchKernelGGL(compositeKdKernel, dim3(numBlocks), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launchRenderKdWide(const RenderArgs &a, int numTiles, int lanesPerRay, bool grad, bool fast, bool surf, hipStream_t s)
 {
   if (numTiles <= 0) return hipSuccess;
@@ -2978,6 +3018,19 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
                       else       hipLaunchKernelGGL((surfacePrepassKdKernel<0, true, false>), grid, block, lds, s, a); }
   else              { if (defer) hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, true>), grid, block, lds, s, a);
                       else       hipLaunchKernelGGL((surfacePrepassKdKernel<0, false, false>), grid, block, lds, s, a); }
+  return hipGetLastError();
+}
+
+// the ambient-occlusion rays of the hits the pre-pass listed (a.aoRecs / a.aoCount); on the pre-pass' stream, or on another
+// one behind an event (the module then runs them beside the march)
+hipError_t launchAoRaysKd(const RenderArgs &a, int numBlocks, hipStream_t s)
+{
+  if (numBlocks <= 0) return hipSuccess;
+  const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + size_t(kKdStack + kSegQueue) * kKdBlock * 12;
+  const dim3 block(kKdBlock);
+  bool isoOnly = a.numTris == 0 && a.numStreamPrims == 0;
+  for (int i = 0; i < EXA_MAX_CONTOUR_PLANES; i++) isoOnly = isoOnly && !a.fs.contour[i].enabled;
+  const bool defer = a.aoRecs && a.aoCount;
   if (defer && a.fs.ao.enabled) {
     const int maxBlocks = 256 * (isoOnly ? EXA_AO_ISO_WAVES : EXA_PREPASS_WAVES);      // what the device holds at once (workgroups per CU = waves per SIMD)
     const long long upper = ((long long)numBlocks * kTilePixels * 2 + kKdBlock - 1) / kKdBlock;
@@ -2985,7 +3038,7 @@ hipError_t launchSurfacePrepassKd(const RenderArgs &a, int numBlocks, bool stats
     if (a.aoKeys) {
       // sorted: histogram of the rays' bins -> scan -> scatter of the ray indices -> trace in that order -> combine per hit
       const dim3 gs((unsigned)(upper < 2048 ? upper : 2048)), b256(256);
-      (void)hipMemsetAsync(a.aoHist, 0, size_t(a.aoBins) * sizeof(uint32_t), s);
+      if (hipError_t e = hipMemsetAsync(a.aoHist, 0, size_t(a.aoBins) * sizeof(uint32_t), s)) return e;   // a stale histogram would send the scatter out of range
       hipLaunchKernelGGL(aoKeyKernel, gs, b256, 0, s, a);
       hipLaunchKernelGGL(aoScanKernel, dim3(1), dim3(1024), 0, s, a.aoHist, a.aoBins);
       hipLaunchKernelGGL(aoScatterKernel, gs, b256, 0, s, a);

@@ -362,6 +362,13 @@ struct ExaHipRenderer {
   hipStream_t side4 = nullptr, side2 = nullptr, sideN = nullptr;
   hipEvent_t evFork = nullptr, evJoin4 = nullptr, evJoin2 = nullptr, evJoinN = nullptr;
   DevBuf<uint32_t> surfRnd;
+  // option ao_overlap (default 1): the deferred AO rays run BESIDE the march instead of in front of it.  The march needs the
+  // surfaces' hit distance up front but their colour only for its very last operation, and the AO launch — as long as its
+  // longest rays, with few waves busy — writes nothing but that colour: the march stores its pixel colour (pixBuf) and a small
+  // kernel finishes the pixels once both are done.  Same operations per pixel, same order.
+  DevBuf<float4> pixBuf;
+  int aoOverlap = 1;
+  hipEvent_t evPre = nullptr, evPre2 = nullptr, evAo = nullptr, evAo2 = nullptr;
   DevBuf<AoRecord> aoRecs;              // deferred AO rays: one record per shaded hit and pixel slot at most
   DevBuf<uint32_t> aoCount;             // [0..3] the frame's list (or the cheap pipeline's), [4..7] the heavy pipeline's
   DevBuf<uint32_t> aoKeys, aoOrder, aoHist;   // ao_defer = 2: bin of every listed ray, ray indices in bin order, 2 x aoBins counters (one set per pipeline)
@@ -955,12 +962,21 @@ struct ExaHipRenderer {
       // pipeline's list starts behind nPreCheap WHOLE tiles (accum.n = W * H on one GPU is smaller when W or H is not a
       // multiple of the tile)
       const size_t recs = size_t(numBlocks) * kTilePixels;
-      if (aoRecs.n != recs) HIP_TRY(this, aoRecs.alloc(recs));
+      bool listOk = true;
+      if (aoRecs.n != recs && aoRecs.alloc(recs) != hipSuccess) {
+        // the list is an optimisation (64 B per pixel): without it the AO rays are traced inline behind each pixel's primary ray
+        (void)hipGetLastError();
+        aoRecs.release();
+        listOk = false;
+        if (std::getenv("EXA_HIP_VERBOSE")) std::fprintf(stderr, "[exa_hip] no memory for the list of deferred AO rays (%zu records): traced inline\n", recs);
+      }
+      if (listOk) {
       if (!aoCount.p) HIP_TRY(this, aoCount.alloc(8));        // per pipeline: [0] listed hits, [2] the AO kernel's chunk counter
       HIP_TRY(this, hipMemsetAsync(aoCount.p, 0, 8 * sizeof(uint32_t), s));
       a.aoRecs = aoRecs.p; a.aoCount = aoCount.p;
+      }
       a.aoKeys = nullptr;
-      if (aoDefer == 2) {
+      if (listOk && aoDefer == 2) {
         // bins: (32x32-pixel blocks of the frame, or groups of four of this shard's tiles) x 24 direction classes
         const uint32_t cells = world <= 1 ? uint32_t((W + 31) / 32) * uint32_t((H + 31) / 32) : uint32_t((numBlocks + 3) / 4);
         const uint32_t bins = std::max(1u, cells) * 24u;
@@ -980,6 +996,13 @@ struct ExaHipRenderer {
       const bool wide = !stats && !emptyCells && nWide4 + nWide2 > 0 && p.numPrimaryChannels == 1 && a.debugPixel < 0;
       const bool split = surfOn && !stats && !wide && costPhase == 0 && !a.tileCost && nPreHeavy > 0 && nPreCheap > 0
                          && nPreHeavy + nPreCheap == numBlocks && a.debugPixel < 0;
+      // the deferred AO rays beside the march (see aoOverlap); the viewer's clock heat map times the march kernel itself and
+      // keeps the plain sequence
+      const bool overlap = aoOverlap && a.aoRecs && fs.ao.enabled && !wide && !(fs.clockScale > 0.f);
+      if (overlap) {
+        if (pixBuf.n != accum.n) HIP_TRY(this, pixBuf.alloc(accum.n));
+        a.pixOut = pixBuf.p;
+      }
       if (split) {
         // two pipelines side by side (see prepassSplit): pre-pass + march of the heavy tiles, pre-pass + march of the rest
         HIP_TRY(this, hipEventRecord(evFork, s));
@@ -998,15 +1021,46 @@ struct ExaHipRenderer {
         HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(ah, nPreHeavy, false, side2));
         HIP_TRY(this, hipStreamWaitEvent(sideN, evFork, 0));
         HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(ac, nPreCheap, false, sideN));
+        if (overlap) {
+          // both pipelines' AO rays on the third side stream, each behind its pre-pass; the marches start at once
+          HIP_TRY(this, hipEventRecord(evPre2, side2));
+          HIP_TRY(this, hipEventRecord(evPre, sideN));
+          HIP_TRY(this, hipStreamWaitEvent(side4, evPre2, 0));
+          HIP_TRY(this, EXA_FORM(launchAoRaysKd)(ah, nPreHeavy, side4));
+          HIP_TRY(this, hipEventRecord(evAo2, side4));
+          HIP_TRY(this, hipStreamWaitEvent(side4, evPre, 0));
+          HIP_TRY(this, EXA_FORM(launchAoRaysKd)(ac, nPreCheap, side4));
+          HIP_TRY(this, hipEventRecord(evAo, side4));
+        } else {
+          HIP_TRY(this, EXA_FORM(launchAoRaysKd)(ah, nPreHeavy, side2));
+          HIP_TRY(this, EXA_FORM(launchAoRaysKd)(ac, nPreCheap, sideN));
+        }
         HIP_TRY(this, march(ac, nPreCheap, true, 0, sideN));
+        if (overlap) {
+          HIP_TRY(this, hipStreamWaitEvent(sideN, evAo, 0));
+          HIP_TRY(this, EXA_FORM(launchCompositeKd)(ac, nPreCheap, sideN));
+        }
         HIP_TRY(this, hipEventRecord(evJoinN, sideN));
         HIP_TRY(this, march(ah, nPreHeavy, true, 0, side2));
+        if (overlap) {
+          HIP_TRY(this, hipStreamWaitEvent(side2, evAo2, 0));
+          HIP_TRY(this, EXA_FORM(launchCompositeKd)(ah, nPreHeavy, side2));
+        }
         HIP_TRY(this, hipEventRecord(evJoin2, side2));
         HIP_TRY(this, hipStreamWaitEvent(s, evJoin2, 0));
         HIP_TRY(this, hipStreamWaitEvent(s, evJoinN, 0));
       } else {
       if (surfOn) HIP_TRY(this, EXA_FORM(launchSurfacePrepassKd)(a, numBlocks, stats, s));
-      if (!wide) {
+      if (surfOn && !stats && !overlap) HIP_TRY(this, EXA_FORM(launchAoRaysKd)(a, numBlocks, s));
+      if (overlap) {
+        HIP_TRY(this, hipEventRecord(evPre, s));
+        HIP_TRY(this, hipStreamWaitEvent(side4, evPre, 0));
+        HIP_TRY(this, EXA_FORM(launchAoRaysKd)(a, numBlocks, side4));
+        HIP_TRY(this, hipEventRecord(evAo, side4));
+        HIP_TRY(this, march(a, numBlocks, true, 0, s));
+        HIP_TRY(this, hipStreamWaitEvent(s, evAo, 0));
+        HIP_TRY(this, EXA_FORM(launchCompositeKd)(a, numBlocks, s));
+      } else if (!wide) {
         HIP_TRY(this, march(a, numBlocks, surfOn, stats ? statsMode : 0, s));
       } else {
         // the critical tiles on side streams so that they start together with the rest of the frame
@@ -1197,6 +1251,10 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
 {
   if (!out || !scene) { g_createError = "exa_hip_create: null argument"; return 1; }
   *out = nullptr;
+  if (scene->allowEmptyCells != 0 && scene->allowEmptyCells != 1) {
+    g_createError = "exa_hip_create: ExaHipScene.allowEmptyCells is 0 or 1 (was the struct zero-initialised before it was filled?)";
+    return 1;
+  }
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) {
@@ -1464,6 +1522,10 @@ int exa_hip_create(const ExaHipScene *scene, int32_t device, ExaHipRenderer **ou
   CREATE_TRY(hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
   CREATE_TRY(hipStreamCreateWithFlags(&h->sideN, hipStreamNonBlocking));
   CREATE_TRY(hipEventCreateWithFlags(&h->evJoinN, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evPre, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evPre2, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evAo, hipEventDisableTiming));
+  CREATE_TRY(hipEventCreateWithFlags(&h->evAo2, hipEventDisableTiming));
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
@@ -1541,6 +1603,7 @@ int exa_hip_destroy(ExaHipRenderer *h)
   if (h->side2) (void)hipStreamDestroy(h->side2);
   if (h->sideN) (void)hipStreamDestroy(h->sideN);
   if (h->evJoinN) (void)hipEventDestroy(h->evJoinN);
+  for (hipEvent_t e : { h->evPre, h->evPre2, h->evAo, h->evAo2 }) if (e) (void)hipEventDestroy(e);
   delete h;
   return 0;
 }
@@ -1775,6 +1838,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
     h->aoDefer = value; return 0;
   }
   if (!std::strcmp(key, "prepass_split")) { h->prepassSplit = value != 0; h->costPhase = 1; return 0; }
+  if (!std::strcmp(key, "ao_overlap")) { h->aoOverlap = value != 0; return 0; }
   if (!std::strcmp(key, "walk_probe")) { h->walkProbeOn = value != 0; return 0; }
   if (!std::strcmp(key, "debug_pixel")) { h->debugPixel = value; return 0; }
   if (!std::strcmp(key, "profile_marker")) {            // an empty kernel on the null stream, visible in a profiler's dispatch list

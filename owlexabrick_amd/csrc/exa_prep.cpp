@@ -309,8 +309,10 @@ int exa_prep_create_ex(const int32_t *bricks7, uint64_t numBricks,
       for (size_t i = b; i < e; i++) {
         const int32_t id = cellIDs[i];
         if (id < 0) {
-          // ALLOW_EMPTY_CELLS (exa/OptixRenderer.cpp:116-121; the loader admits -1 only, exa/ExaBricks.cpp:46-49)
-          if (allowEmpty && id == -1) dst[i] = EXA_EMPTY_CELL_POISON_VALUE; else bad = 1;
+          // ALLOW_EMPTY_CELLS: the renderer poisons EVERY negative id (exa/OptixRenderer.cpp:116-118).  That only -1 means
+          // "no cell" is an assert of the loader (exa/ExaBricks.cpp:46-49) — compiled out of a release build, so a bricks
+          // file the reference's release binary renders is rendered here as well.
+          if (allowEmpty) dst[i] = EXA_EMPTY_CELL_POISON_VALUE; else bad = 1;
           continue;
         }
         if (uint64_t(id) >= len) { bad = 2; continue; }

@@ -3,7 +3,7 @@
 A case of tests/fuzz_cases.py at a frame of 8..60 tiles, rendered (2 accumulated frames) with the defaults, then again
 with a random launch order, with the cost feedback in its three phases, with every tile on the wide march (2 and 4 lanes
 per ray; one primary channel only), with the memory layouts and launch plans of round 3 toggled (brick order, channel
-interleaving, 64-bit addresses, the split pre-pass plan), as the shards of a random number of ranks re-assembled by the device untile kernel
+interleaving, 64-bit addresses, the split pre-pass plan), with either walk of the kd path and the AO rays in front of or beside the march (round 5), as the shards of a random number of ranks re-assembled by the device untile kernel
 and by its host mirror, and through a multi-device handle: every one must give the same RGBA8 frame and the same
 accumulation buffer bit for bit."""
 import sys
@@ -57,7 +57,9 @@ def check(seed):
         R.setOption("wide_march", 1)
     # round 3: where the cells lie in memory and how a frame with surfaces is launched (round 4: ao_defer 2 = sorted AO rays)
     for key, val in (("brick_order", 1), ("interleave", 0), ("addr64", 1), ("prepass_split", 0), ("brick_order", 0), ("interleave", 1),
-                     ("prepass_split", 1), ("addr64", 0), ("ao_defer", 0), ("ao_defer", 2), ("ao_defer", 1)):
+                     ("prepass_split", 1), ("addr64", 0), ("ao_defer", 0), ("ao_defer", 2), ("ao_defer", 1),
+                     # round 5: which walk the march takes, and whether the AO rays run beside it
+                     ("walk", 1), ("walk", 2), ("ao_overlap", 0), ("walk", 0), ("ao_overlap", 1)):
         R.setOption(key, val)
         for k in range(2 if key == "prepass_split" else 1):      # the plan changes after its measuring frame
             if not _same(_frames(R), base):

@@ -93,7 +93,56 @@ def test_pmc_frame_totals_sum_the_kernels_of_a_frame(tmp_path):
     tot, frames = bench.pmc_frame_totals([str(f)], frames=2)
     assert frames == 2 and tot == {"march": {"SQ_INSTS_VALU": 30.0}, "surfaces_prepass": {"SQ_INSTS_VALU": 3.0},
                                    "ao_rays": {"SQ_INSTS_VALU": 4.0}}
+    # the march's kernel name with the walk in it (round 5: <GRAD, FAST, MULTI, SURF, STATS, SMALL, NCH, ROPE>)
+    rope = "void exa::form1::renderFrameKdKernel<true, true, 0, false, 0, true, 0, true>(exa::RenderArgs)"
+    rope_counted = "void exa::form1::renderFrameKdKernel<true, true, 0, false, 1, false, 0, true>(exa::RenderArgs)"
+    assert re.search(bench.FRAME_KERNELS["march"], rope) and not re.search(bench.FRAME_KERNELS["march"], rope_counted)
     lbvh = "void exa::form1::renderFrameKernel<true, true, 0>(exa::RenderArgs)"
     f.write_text(rows[0] + f'\n1,1,0,"{lbvh}",SQ_INSTS_VALU,3.0\n')
     assert bench.pmc_frame_totals([str(f)]) == ({"march": {"SQ_INSTS_VALU": 3.0}}, 1)
     assert bench.pmc_frame_totals([]) == ({}, 0)
+
+
+def test_pmc_frame_count_of_a_frame_with_surfaces_real_dispatch_list():
+    """tests/golden/pmc_c3iso_pass1_counter_collection.csv: the tail of a real `rocprofv3 --pmc WRITE_SIZE SQ_INSTS_VALU` list
+    of a bench.py child on C3 + iso-surface (two timed frames between the two marker dispatches, each frame the split
+    pre-pass plan: two pre-pass and two march dispatches; trimmed to the columns the parser reads).  The frame count is the
+    caller's (steps x spp): counted from the march dispatches it came out twice too large in round 4."""
+    import bench
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pmc_c3iso_pass1_counter_collection.csv")
+    tot, frames = bench.pmc_frame_totals([f], frames=2, need_bracket=True)
+    assert frames == 2
+    assert tot["march"]["SQ_INSTS_VALU"] == 10738573131.0 and tot["surfaces_prepass"]["SQ_INSTS_VALU"] == 265317793.0
+    # the fallback (dispatch counting) sees four march dispatches between the markers: half the instructions per "frame"
+    tot_fb, frames_fb = bench.pmc_frame_totals([f])
+    assert frames_fb == 4 and tot_fb["march"]["SQ_INSTS_VALU"] == tot["march"]["SQ_INSTS_VALU"] / 2
+    # ... which is why a bracketed child never falls back: no frame count, or no bracket, is an error
+    import pytest
+    with pytest.raises(bench.PmcBracketError):
+        bench.pmc_frame_totals([f], frames=None, need_bracket=True)
+    lines = [ln for ln in open(f).read().splitlines() if "profileMarkerKernel" not in ln]
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix="_counter_collection.csv", delete=False) as g:
+        g.write("\n".join(lines) + "\n")
+    try:
+        with pytest.raises(bench.PmcBracketError):
+            bench.pmc_frame_totals([g.name], frames=2, need_bracket=True)
+    finally:
+        os.unlink(g.name)
+
+
+def test_pmc_child_that_the_profiler_refuses_is_ended_at_once(tmp_path, monkeypatch):
+    """a counter request the hardware cannot serve: the profiler's tool library prints its refusal, aborts the child and then
+    hangs in its own finalisation (round 4 record).  live_pmc must not sit out its time limit: it ends the child's process
+    group as soon as the refusal shows on stderr and reports it."""
+    import shutil
+    import bench
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/bash\necho 'Could not construct profile cfg failed with error code 38: Request exceeds the capabilities "
+                    "of the hardware to collect' >&2\nsleep 120\n")
+    fake.chmod(0o755)
+    monkeypatch.setattr(shutil, "which", lambda name: str(fake))
+    t = time.time()
+    vals, why = bench.live_pmc(["--steps", "1"], seconds=60.0, frames=1)
+    assert vals is None and "refused by the profiler" in why and "error code 38" in why
+    assert time.time() - t < 20.0

@@ -89,10 +89,19 @@ def test_empty_cells_are_an_error_without_the_option():
         binding.Prep(sc)
     with pytest.raises(RuntimeError, match="overflow in index vector"):
         po.OracleScene(sc.bricks7, sc.cellIDs, sc.fields)
+    # with the option EVERY negative id is "no cell", as in the renderer (OptixRenderer.cpp:116-118; "-1 only" is an assert of
+    # the loader, compiled out of a release build): prep and oracle agree byte for byte on such a file
     ids = np.array(sc.cellIDs, copy=True)
-    ids[ids < 0] = -7                                                             # only -1 means "empty" (ExaBricks.cpp:46-49)
+    ids[ids < 0] = -7
+    odd = scenes.Scene(sc.bricks7, ids, sc.fields)
+    P = binding.Prep(odd, allow_empty_cells=True)
+    S = po.OracleScene(odd.bricks7, odd.cellIDs, odd.fields, allow_empty_cells=True)
+    P1 = binding.Prep(sc, allow_empty_cells=True)
+    assert P.scalars().tobytes() == S.scalars().tobytes() == P1.scalars().tobytes()
+    assert P.regions().tobytes() == S.regions().tobytes()
+    P.close(); P1.close()
     with pytest.raises(RuntimeError, match="overflow in index vector"):
-        binding.Prep(scenes.Scene(sc.bricks7, ids, sc.fields), allow_empty_cells=True)
+        binding.Prep(odd)
 
 
 def test_scene_with_empty_cells_keeps_the_source_order():
@@ -105,3 +114,19 @@ def test_scene_with_empty_cells_keeps_the_source_order():
     _, acc, _ = S.render(fs, P, 48, 32)
     assert np.array_equal(acc, a[1])
     assert np.isfinite(a[1]).all() and a[1][..., :3].sum() > 0
+
+
+def test_create_refuses_a_scene_struct_with_garbage_in_allow_empty_cells():
+    """ExaHipScene.allowEmptyCells sits where the struct used to end in padding: a caller that fills the struct field by
+    field without zeroing it passes whatever was there.  Anything but 0 / 1 is refused (before a device is touched),
+    instead of silently switching the scene to the empty-cells kernels."""
+    import ctypes as C
+    L = binding.lib()
+    P = binding.Prep(scenes.example("ex3"))
+    sc = binding.ExaHipScene.from_buffer_copy(P.scene)
+    sc.allowEmptyCells = 0x5a5a5a5a
+    h = C.c_void_p()
+    assert L.exa_hip_create(C.byref(sc), 0, C.byref(h)) != 0 and not h.value
+    L.exa_hip_last_error.restype = C.c_char_p
+    assert b"allowEmptyCells" in L.exa_hip_last_error(None)
+    P.close()
