@@ -4,7 +4,7 @@ set -o pipefail
 O=gpurun_out
 stop() { rc=$1; if [ "$rc" -ge 124 ]; then echo "step killed (rc $rc): stopping"; exit "$rc"; fi; }
 timeout -k 10 900 python bench.py > $O/r05_z_bench.json 2> $O/r05_z_bench.err; stop $?; tail -c 600 $O/r05_z_bench.json; echo
-timeout -k 10 400 bash tools/config_timeline.sh $O/r05_z_tl_c4 --steps 10 --pmc off | cut -c1-220; stop $?
+timeout -k 10 400 bash tools/config_timeline.sh $O/r05_z_tl_c4 --steps 10 --pmc off --in-flight 1 | cut -c1-220; stop $?
 timeout -k 10 1100 bash tools/pmc_run.sh $O/r05_z_pmc_c4 --pmc off --in-flight 1 > $O/r05_z_pmc_c4.txt 2>&1; stop $?
 grep -E "^==|SQ_INSTS_VALU |lane util|WAVE_CYCLES|FETCH_SIZE .*GB|L2 hit|L1 miss" $O/r05_z_pmc_c4.txt | head -24
 b() { name=$1; shift; timeout -k 10 700 python bench.py --cpu-baseline off --pmc on "$@" > $O/r05_z_$name.json 2> $O/r05_z_$name.err; rc=$?; stop $rc; [ $rc -ne 0 ] && tail -3 $O/r05_z_$name.err; }
