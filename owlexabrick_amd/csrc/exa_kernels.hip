@@ -2463,25 +2463,8 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         }
         w.pk.clearField(PK_NEEDHDR);
       }
-#ifndef EXA_MARCH_PAIR
-#define EXA_MARCH_PAIR 0     // experiment (profiles/r05_experiments.txt): two consecutive samples of a one-brick segment per iteration
-#endif
-      // EXA_MARCH_PAIR: a lane in a one-brick region whose segment goes on behind this sample also evaluates the NEXT sample's
-      // sums in this iteration (same position arithmetic as the step advance below), so that both samples' cell loads are in
-      // flight together; its epilogue follows this sample's (and is dropped with the ray if this sample ends it): same pixels.
-      constexpr bool PAIR = EXA_MARCH_PAIR && !MULTI && !NCH && STATS == 0;
-      Basis B2;
-      B2.sumWV = 0.f; B2.sumW = 0.f; B2.sumD = mk(0.f, 0.f, 0.f); B2.sumDC = mk(0.f, 0.f, 0.f);
-      const bool pairLane = PAIR && listSize == 1 && fminf(t_i, t1) < t1;
-      if (PAIR && anyLane(pairLane)) {
-        const V3 posA = rayAt(ray.org, t_sample, ray.dir);
-        const float tlB = fminf(t_i, t1);
-        const float tnB = fminf(t_i + a.p.dt * flcw, t1);
-        const float tsB = 0.5f * (fminf(t1, tnB) + tlB);
-        const V3 posB = pairLane ? rayAt(ray.org, tsB, ray.dir) : posA;      // (a lane without a second sample repeats its first: discarded)
-        addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, field0, posA);
-        addBasisFast<GRAD, STATS, SMALL>(C, B2, hb0, hb1, field0, posB);
-      } else
+      // (two consecutive samples of a one-brick segment per iteration, so that both samples' cell loads are in flight together, was
+      // built and measured at 5 and 4 waves per SIMD: C4 17.34 -> 25.05 ms; profiles/r05_experiments.txt 9)
       if (NCH) addBasisFastIl<GRAD, SMALL, (NCH ? NCH : 2)>(B, xWV, xD, hb0, hb1, a.cellsIl, rayAt(ray.org, t_sample, ray.dir));
       else addBasisFast<GRAD, STATS, SMALL>(C, B, hb0, hb1, MULTI ? field : field0, rayAt(ray.org, t_sample, ray.dir));   // :1166
       child++;
@@ -2544,33 +2527,6 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         actual_dt = t_next - t_last;
       }
       C.count(ST_SAMPLE_EVALS);
-      if (PAIR && pairLane) {
-        // the step just set up is the one whose sums this iteration already holds (B2): finish it as well
-        if (B2.sumW > 1e-20f) {
-          const float cellValue = fdivExact<FAST>(B2.sumWV, B2.sumW);
-          V3 grad = mk(0.f, 0.f, 0.f);
-          if (GRAD) grad = gradOf(B2.sumW, B2.sumWV, B2.sumD, B2.sumDC);
-          integrateVolume<FAST, STATS, FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, 0, xfRcpRange0);
-        }
-        if (pixelColor.w >= EXA_TERMINATION_THRESHOLD) {
-          pixelColor.x = pixelColor.x * pixelColor.w;
-          pixelColor.y = pixelColor.y * pixelColor.w;
-          pixelColor.z = pixelColor.z * pixelColor.w;
-          pixelColor.w = 1.f;
-          break;
-        }
-        const float t_last2 = fminf(t_i, t1);
-        if (t_last2 >= t1) {
-          haveSeg = false;
-          continue;
-        }
-        t_i += a.p.dt * flcw;
-        {
-          const float t_next = fminf(t_i, t1);
-          t_sample = 0.5f * (fminf(t1, t_next) + t_last2);
-          actual_dt = t_next - t_last2;
-        }
-      }
     }
 
     C.lap(ST_T_OTHER);
