@@ -93,8 +93,10 @@ def check(seed):
             cam = case.cam(vlo, vhi)                                # the viewer re-derives the screen vectors (viewer.cpp:442-450)
             R.updateCamera(cam["pos"], cam["dir00"], cam["dirDu"], cam["dirDv"])
         elif op == "accel":
-            case.accel = int(rng.integers(0, 2))
-            R.setOption("accel", case.accel)
+            case.accel = int(rng.integers(0, 3))           # LBVH restart, kd-tree stack walk, kd-tree rope walk
+            R.setOption("accel", 1 if case.accel else 0)
+            if case.accel:
+                R.setOption("walk", case.accel)
         live = _frames(R)
         F = case.hip_renderer()
         fresh = _frames(F)
