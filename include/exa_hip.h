@@ -179,6 +179,14 @@ void exa_prep_destroy(ExaPrep *);
 /* fills an ExaHipScene whose pointers stay valid until exa_prep_destroy */
 int  exa_prep_scene(const ExaPrep *, ExaHipScene *out);
 const char *exa_prep_last_error(void);
+/* diagnostic: the leaves and neighbour links exa_hip builds for its rope walk (option "walk") from this scene's kd-tree, on the
+ * host (owlexabrick_amd/csrc/exa_ropes.h).  Call with leafBoxes == NULL for the counts, then with arrays of that size:
+ * leafBoxes numLeaves x 6 floats (lo, hi), leafLinks numLeaves x 6 (-x +x -y +y -z +z: inner node >= 0, leaf ~index, outside
+ * the root box = EXA_KD_EMPTY + 1), leafRegion numLeaves (region id; -1: a gap = an empty child slot of the tree), nodes
+ * numNodes (the tree behind the links: no empty slots).  *flags: bit 0 = every region leaf's box is its domain, bit 1 = the
+ * planes are in the range of the walk's short exact division. */
+int exa_prep_ropes(const ExaPrep *, uint64_t *numLeaves, uint64_t *numNodes, float *leafBoxes, int32_t *leafLinks,
+                   int32_t *leafRegion, ExaKdNode *nodes, int32_t *flags);
 
 /* ------------------------------------------------------------------ */
 /* device module                                                       */

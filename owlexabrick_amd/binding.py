@@ -89,7 +89,7 @@ KDNODE_DTYPE = np.dtype([("split", "<f4"), ("axis", "<i4"), ("left", "<i4"), ("r
 KD_EMPTY = -2 ** 31
 
 # every symbol include/exa_hip.h declares
-ABI_SYMBOLS = ["exa_prep_create", "exa_prep_create_ex", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error",
+ABI_SYMBOLS = ["exa_prep_create", "exa_prep_create_ex", "exa_prep_destroy", "exa_prep_scene", "exa_prep_last_error", "exa_prep_ropes",
                "exa_hip_create", "exa_hip_create_multi", "exa_hip_destroy", "exa_hip_resize", "exa_hip_set_frame_state",
                "exa_hip_set_xf", "exa_hip_set_triangles", "exa_hip_reset_tracer", "exa_hip_set_tracer_enabled",
                "exa_hip_advance_tracer", "exa_hip_read_traces", "exa_hip_set_params", "exa_hip_set_shard", "exa_hip_output_pixels",
@@ -108,7 +108,7 @@ def lib():
             # not built yet: try to build the HIP module (hipcc cross-compiles without a GPU); never a CPU fallback
             import subprocess
             try:
-                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j4"])
+                subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-s", "-j6"])
             except Exception as e:  # noqa: BLE001
                 raise RuntimeError(f"{LIB_PATH} not found and building it failed ({e}); run "
                                    "__graft_entry__.build(); there is no CPU fallback") from e
@@ -121,6 +121,7 @@ def lib():
         L.exa_prep_create_ex.argtypes = [vp, C.c_uint64, vp, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64),
                                          C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
         L.exa_prep_destroy.argtypes = [vp]
+        L.exa_prep_ropes.argtypes = [vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), vp, vp, vp, vp, C.POINTER(C.c_int32)]
         L.exa_prep_scene.argtypes = [vp, C.POINTER(ExaHipScene)]
         L.exa_prep_last_error.restype = C.c_char_p
         L.exa_hip_create.argtypes = [C.POINTER(ExaHipScene), C.c_int32, C.POINTER(vp)]
@@ -195,6 +196,21 @@ class Prep:
 
     def kd_nodes(self):
         return self._arr(self.scene.kdNodes, self.scene.numKdNodes, KDNODE_DTYPE)
+
+    def ropes(self):
+        """leaves and neighbour links of the rope walk as the module builds them (exa_prep_ropes, a diagnostic):
+        dict(boxes [n,6], links [n,6], region [n], nodes (KDNODE_DTYPE), flags)"""
+        nl, nn, flags = C.c_uint64(0), C.c_uint64(0), C.c_int32(0)
+        if lib().exa_prep_ropes(self.h, C.byref(nl), C.byref(nn), None, None, None, None, None):
+            raise RuntimeError(lib().exa_prep_last_error().decode())
+        boxes = np.zeros((nl.value, 6), dtype=np.float32)
+        links = np.zeros((nl.value, 6), dtype=np.int32)
+        region = np.zeros(nl.value, dtype=np.int32)
+        nodes = np.zeros(max(1, nn.value), dtype=KDNODE_DTYPE)
+        if lib().exa_prep_ropes(self.h, C.byref(nl), C.byref(nn), boxes.ctypes.data, links.ctypes.data, region.ctypes.data,
+                                nodes.ctypes.data, C.byref(flags)):
+            raise RuntimeError(lib().exa_prep_last_error().decode())
+        return dict(boxes=boxes, links=links, region=region, nodes=nodes[:nn.value], flags=int(flags.value))
 
     def voxel_bounds(self):
         return (np.array(self.scene.voxelBounds_lo, dtype=np.float32),

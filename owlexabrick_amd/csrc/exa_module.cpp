@@ -3,6 +3,7 @@
 // exa/OptixRenderer.cpp does through OWL/OptiX; see include/exa_hip.h for the
 // per-entry citations.
 #include "exa_device.h"
+#include "exa_ropes.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -1100,132 +1101,49 @@ struct ExaHipRenderer {
   }
 };
 
-// Leaves and neighbour links of the rope walk, from the region kd-tree and the regions' domains as the device holds
-// them.  One top-down pass: a node hands each child its box and its six links (the child's sibling across the split
-// plane, the parent's links elsewhere), and every link is pushed down as far as it stays unambiguous — into the child
-// next to the face while the linked node splits along the face's axis, or into the one child whose side of a split the
-// whole face lies on (Popov et al. 2007, "Stackless kd-tree traversal").  Empty child slots of the tree (space no brick
-// covers) become gap leaves, so that a ray can pass through them.  The top levels are expanded serially, the subtrees
-// below them by a pool of threads.
+// Leaves and neighbour links of the rope walk (exa_ropes.h), from the region kd-tree and the regions' domains as the device
+// holds them; this adds what the march needs of a region (its packed record) and uploads the result.
 int ExaHipRenderer::buildRopes()
 {
   const auto tBuild0 = std::chrono::steady_clock::now();
   const size_t nk = kdNodes.n, nr = sc.numRegions;
-  std::vector<KdNodeDev> rn(nk);
+  static_assert(sizeof(KdNodeDev) == sizeof(ExaKdNode), "the device's kd node is the ABI's with activity bits in the axis word");
+  std::vector<ExaKdNode> kd(nk);
   std::vector<float> dom(6 * nr);
   std::vector<RegionInfo> ri(nr);
-  if (nk) HIP_TRY(this, hipMemcpy(rn.data(), kdNodes.p, nk * sizeof(KdNodeDev), hipMemcpyDeviceToHost));
+  if (nk) HIP_TRY(this, hipMemcpy(kd.data(), kdNodes.p, nk * sizeof(KdNodeDev), hipMemcpyDeviceToHost));
   HIP_TRY(this, hipMemcpy(dom.data(), domain.p, dom.size() * sizeof(float), hipMemcpyDeviceToHost));
   HIP_TRY(this, hipMemcpy(ri.data(), regionInfo.p, nr * sizeof(RegionInfo), hipMemcpyDeviceToHost));
-  // the tree the walk descends in: activity bits dropped, every empty child slot a gap leaf of its own
-  size_t gaps = 0;
-  for (KdNodeDev &n : rn) {
-    n.word &= 3u;
-    if (n.left == EXA_KD_EMPTY) n.left = ~int32_t(nr + gaps++);
-    if (n.right == EXA_KD_EMPTY) n.right = ~int32_t(nr + gaps++);
-  }
-  if (nr + gaps >= 0x7ffffff0ull) { ropeFailed = true; return 0; }
-  // the short exact division of the walk needs planes of moderate size on a binary grid (exa_kernels.hip: ropeStep)
-  bool planesOk = true;
-  for (float v : dom) planesOk = planesOk && std::isfinite(v) && std::fabs(v) <= 1073741824.f && v * 1024.f == std::nearbyint(v * 1024.f);
-  std::vector<RopeLeaf> leaves(nr + gaps);
-  struct Item { int32_t ref; float lo[3], hi[3]; int32_t rope[6]; };
-  std::atomic<bool> bad{false};
-  const uint32_t bb = leafBeginBits, sb = leafSizeBits;
-  auto emitLeaf = [&](const Item &it) {
-    const size_t id = size_t(~it.ref);
-    RopeLeaf &L = leaves[id];
-    L.lo[0] = it.lo[0]; L.lo[1] = it.lo[1]; L.lo[2] = it.lo[2];
-    L.hi0 = it.hi[0]; L.hi1 = it.hi[1]; L.hi2 = it.hi[2];
-    for (int f = 0; f < 6; f++) L.rope[f] = it.rope[f];
-    L.flags = 0; L.pad = 0;
-    if (id < nr) {
-      // the box the splits leave must be the region's domain, float for float: the slab test runs on it
-      for (int k = 0; k < 3; k++) if (dom[6 * id + k] != it.lo[k] || dom[6 * id + 3 + k] != it.hi[k]) bad = true;
-      L.region = (int32_t)id;
-      L.rec = (uint32_t)id;
-      if (bb) {
-        int lv = 0;
-        while (float(1 << lv) < ri[id].finestLevelCellWidth) lv++;
-        L.rec = uint32_t(ri[id].listBegin) | (uint32_t(ri[id].listSize - 1) << bb) | (uint32_t(lv) << (bb + sb));
-      }
-    } else {
-      L.region = -1; L.rec = 0;
-    }
-  };
-  // pushes the links of a box down (see above)
-  auto settle = [&](Item &it) {
-    for (int f = 0; f < 6; f++) {
-      const int fa = f >> 1;
-      const bool upper = (f & 1) != 0;
-      int32_t r = it.rope[f];
-      while (r >= 0) {
-        const KdNodeDev &n = rn[r];
-        const int ax = int(n.word);
-        if (ax == fa) r = upper ? n.left : n.right;              // the child that touches the face
-        else if (n.split >= it.hi[ax]) r = n.left;               // the face lies on the lower side of this split
-        else if (n.split <= it.lo[ax]) r = n.right;              // ... on the upper side
-        else break;
-      }
-      it.rope[f] = r;
-    }
-  };
-  // one node: its two children with their boxes and links
-  auto expand = [&](const Item &it, Item &L, Item &R) {
-    const KdNodeDev &n = rn[it.ref];
-    const int ax = int(n.word);
-    L = it; R = it;
-    L.ref = n.left; R.ref = n.right;
-    L.hi[ax] = n.split; R.lo[ax] = n.split;
-    L.rope[2 * ax + 1] = n.right;
-    R.rope[2 * ax] = n.left;
-    settle(L); settle(R);
-  };
-  auto subtree = [&](const Item &root) {
-    std::vector<Item> stack(1, root);
-    Item L, R;
-    while (!stack.empty()) {
-      const Item it = stack.back();
-      stack.pop_back();
-      if (it.ref < 0) { emitLeaf(it); continue; }
-      expand(it, L, R);
-      stack.push_back(L); stack.push_back(R);
-    }
-  };
-  Item root{};
-  root.ref = kdRoot;
-  for (int k = 0; k < 3; k++) { root.lo[k] = kdLo[k]; root.hi[k] = kdHi[k]; }
-  for (int f = 0; f < 6; f++) root.rope[f] = EXA_KD_EMPTY + 1;   // outside the root box: the walk is done
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned nthreads = nk < 4096 ? 1u : std::min(16u, hw);
-  std::vector<Item> frontier(1, root);
-  while (nthreads > 1 && frontier.size() < 64 * size_t(nthreads)) {
-    std::vector<Item> next;
-    bool any = false;
-    for (const Item &it : frontier) {
-      if (it.ref < 0) { next.push_back(it); continue; }
-      Item L, R;
-      expand(it, L, R);
-      next.push_back(L); next.push_back(R);
-      any = true;
-    }
-    frontier.swap(next);
-    if (!any) break;
-  }
-  std::atomic<size_t> cursor{0};
-  auto worker = [&] { for (size_t i; (i = cursor.fetch_add(1)) < frontier.size();) subtree(frontier[i]); };
-  if (nthreads > 1) {
-    std::vector<std::thread> pool;
-    for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(worker);
-    for (auto &t : pool) t.join();
-  } else worker();
-  if (bad) {
+  const unsigned nthreads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+  RopeBuild rb;
+  buildRopesHost(kd.data(), nk, kdRoot, dom.data(), nr, kdLo, kdHi, nthreads, rb);
+  if (rb.leaves.size() >= 0x7ffffff0ull) { ropeFailed = true; return 0; }
+  if (!rb.boxesMatch) {
     // a tree whose planes do not reproduce the regions' domains (a caller's own kd-tree): the stack walk stays
     if (std::getenv("EXA_HIP_VERBOSE")) std::fprintf(stderr, "[exa_hip] rope walk: the kd-tree's planes do not reproduce the region domains; stack walk kept\n");
     ropeFailed = true;
     return 0;
   }
-  if (ropeLeaves.upload(leaves.data(), leaves.size()) != hipSuccess || ropeNodes.upload(rn.data(), rn.size()) != hipSuccess) {
+  std::vector<RopeLeaf> leaves(rb.leaves.size());
+  const uint32_t bb = leafBeginBits, sb = leafSizeBits;
+  for (size_t id = 0; id < leaves.size(); id++) {
+    const RopeLeafHost &H = rb.leaves[id];
+    RopeLeaf &L = leaves[id];
+    L.lo[0] = H.lo[0]; L.lo[1] = H.lo[1]; L.lo[2] = H.lo[2];
+    L.hi0 = H.hi[0]; L.hi1 = H.hi[1]; L.hi2 = H.hi[2];
+    for (int f = 0; f < 6; f++) L.rope[f] = H.rope[f];
+    L.flags = 0; L.pad = 0;
+    L.region = H.region;
+    L.rec = H.region >= 0 ? (uint32_t)H.region : 0u;
+    if (H.region >= 0 && bb) {
+      int lv = 0;
+      while (float(1 << lv) < ri[id].finestLevelCellWidth) lv++;
+      L.rec = uint32_t(ri[id].listBegin) | (uint32_t(ri[id].listSize - 1) << bb) | (uint32_t(lv) << (bb + sb));
+    }
+  }
+  static_assert(sizeof(ExaKdNode) == 16, "kd node = one 16-byte load");
+  if (ropeLeaves.upload(leaves.data(), leaves.size()) != hipSuccess
+      || ropeNodes.upload(reinterpret_cast<const KdNodeDev *>(rb.nodes.data()), rb.nodes.size()) != hipSuccess) {
     // the links are an optimisation (64 B per leaf + 16 B per node of extra memory): without them the stack walk
     (void)hipGetLastError();
     ropeLeaves.release(); ropeNodes.release();
@@ -1233,13 +1151,13 @@ int ExaHipRenderer::buildRopes()
     return 0;
   }
   ropeRoot = kdRoot;
-  ropeFastDiv = planesOk ? 1 : 0;
-  ropeAddr32 = (leaves.size() * sizeof(RopeLeaf) < (1ull << 32) && rn.size() * sizeof(KdNodeDev) < (1ull << 32)) ? 1 : 0;
+  ropeFastDiv = rb.planesOnGrid ? 1 : 0;
+  ropeAddr32 = (leaves.size() * sizeof(RopeLeaf) < (1ull << 32) && rb.nodes.size() * sizeof(KdNodeDev) < (1ull << 32)) ? 1 : 0;
   ropeBuilt = true;
   ropeFlagsStale = true;
   if (std::getenv("EXA_HIP_VERBOSE"))
-    std::fprintf(stderr, "[exa_hip] rope walk: %zu leaves (%zu gaps), %zu nodes linked on %u threads in %.1f ms; short division %s\n", leaves.size(), gaps,
-                 rn.size(), nthreads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBuild0).count(), planesOk ? "on" : "off");
+    std::fprintf(stderr, "[exa_hip] rope walk: %zu leaves (%zu gaps), %zu nodes linked on %u threads in %.1f ms; short division %s\n", leaves.size(), rb.gaps,
+                 rb.nodes.size(), nthreads, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tBuild0).count(), rb.planesOnGrid ? "on" : "off");
   return 0;
 }
 

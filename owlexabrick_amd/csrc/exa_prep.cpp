@@ -8,6 +8,7 @@
 // (right subtree before left, exa/Regions.cpp:173-178), so region ids, leaf-list
 // offsets and every float are the same as the reference would produce.
 #include "../../include/exa_hip.h"
+#include "exa_ropes.h"
 
 #include <algorithm>
 #include <atomic>
@@ -364,6 +365,37 @@ int exa_prep_create_ex(const int32_t *bricks7, uint64_t numBricks,
 }
 
 void exa_prep_destroy(ExaPrep *P) { delete P; }
+
+// Diagnostic (tests/test_ropes.py): the leaves and links exa_hip builds for its rope walk from this scene's kd-tree, on the
+// host.  First call with leaves == NULL to learn the counts, then with arrays of that size:
+// leafBoxes numLeaves x 6 floats (lo, hi), leafLinks numLeaves x 6 (-x +x -y +y -z +z: inner node >= 0, leaf ~i, outside =
+// EXA_KD_EMPTY + 1), leafRegion numLeaves (region id, -1 for a gap), nodes numNodes (no empty slots).  flags out: bit 0 the
+// boxes equal the region domains, bit 1 the planes are in the short division's range.
+int exa_prep_ropes(const ExaPrep *P, uint64_t *numLeaves, uint64_t *numNodes, float *leafBoxes, int32_t *leafLinks, int32_t *leafRegion,
+                   ExaKdNode *nodes, int32_t *flags)
+{
+  if (!P || !numLeaves || !numNodes) return 1;
+  std::vector<float> dom(6 * P->regions.size());
+  float lo[3] = { INFINITY, INFINITY, INFINITY }, hi[3] = { -INFINITY, -INFINITY, -INFINITY };
+  for (size_t r = 0; r < P->regions.size(); r++)
+    for (int k = 0; k < 3; k++) {
+      dom[6 * r + k] = P->regions[r].domain_lo[k]; dom[6 * r + 3 + k] = P->regions[r].domain_hi[k];
+      lo[k] = std::fmin(lo[k], P->regions[r].domain_lo[k]); hi[k] = std::fmax(hi[k], P->regions[r].domain_hi[k]);
+    }
+  exa::RopeBuild rb;
+  exa::buildRopesHost(P->kdNodes.data(), P->kdNodes.size(), P->kdRoot, dom.data(), P->regions.size(), lo, hi,
+                      std::max(1u, std::thread::hardware_concurrency()), rb);
+  if (!leafBoxes) { *numLeaves = rb.leaves.size(); *numNodes = rb.nodes.size(); return 0; }
+  if (*numLeaves != rb.leaves.size() || *numNodes != rb.nodes.size()) { g_prepError = "exa_prep_ropes: array sizes do not match the counts"; return 1; }
+  for (size_t i = 0; i < rb.leaves.size(); i++) {
+    for (int k = 0; k < 3; k++) { leafBoxes[6 * i + k] = rb.leaves[i].lo[k]; leafBoxes[6 * i + 3 + k] = rb.leaves[i].hi[k]; }
+    for (int f = 0; f < 6; f++) leafLinks[6 * i + f] = rb.leaves[i].rope[f];
+    leafRegion[i] = rb.leaves[i].region;
+  }
+  if (nodes) std::copy(rb.nodes.begin(), rb.nodes.end(), nodes);
+  if (flags) *flags = (rb.boxesMatch ? 1 : 0) | (rb.planesOnGrid ? 2 : 0);
+  return 0;
+}
 
 int exa_prep_scene(const ExaPrep *P, ExaHipScene *out)
 {

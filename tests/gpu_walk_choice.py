@@ -13,7 +13,10 @@ from owlexabrick_amd import harness, scenes
 name = sys.argv[1] if len(sys.argv) > 1 else "c4_exajet"
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 sc = scenes.config(name)
-case = Case(sc, W=size, H=size, grad=1, xf_domains=[(0.0, 1.0)] * len(sc.fields))
+holes = float(os.environ.get("EXA_WALK_HOLES", "0"))          # > 0: that fraction of the cells missing (the ALLOW_EMPTY_CELLS kernels)
+if holes > 0:
+    sc = scenes.with_empty_cells(sc, fraction=holes, seed=1)
+case = Case(sc, W=size, H=size, grad=1, xf_domains=[(0.0, 1.0)] * len(sc.fields), allow_empty_cells=holes > 0)
 R = case.hip_renderer()
 t = np.arange(128) / 127.0
 

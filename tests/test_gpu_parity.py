@@ -501,3 +501,25 @@ def test_one_region_scene_skips_its_region_when_inactive(accel):
             assert h[2]["segments"] == expect_seg
         if "iso" in kw:
             assert h[2]["iso_segments"] == 0 and o[2]["iso_segments"] == 0
+
+
+def test_walk_is_chosen_from_the_fraction_of_active_regions():
+    """option walk = 0 (default): the rope walk when at least half of the regions are active for the volume march, else the
+    stack walk, which prunes inactive subtrees (the rope walk passes through every leaf on the ray).  The counting variant
+    tells which one ran (walk_leaf_visits); either way the frame is the same bit for bit."""
+    sc = _amr()
+    dense, sparse = Case(sc, W=96, H=96, grad=1), Case(sc, W=96, H=96, grad=1, xf=band_xf(0.45, 0.5))
+    for case, want_rope in ((dense, True), (sparse, False)):
+        R = case.hip_renderer()
+        frac = float(R.readActivity(0).mean())
+        assert (frac >= 0.5) == want_rope, frac
+        rgba, st = R.renderStats()
+        acc = R.readAccum().copy()
+        assert (st["walk_leaf_visits"] > 0) == want_rope and (st["walk_restarts"] == 0 or not want_rope)
+        for walk in (1, 2):
+            R.setOption("walk", walk)
+            rgba_w, st_w = R.renderStats()
+            assert (st_w["walk_leaf_visits"] > 0) == (walk == 2)
+            assert np.array_equal(rgba_w, rgba) and np.array_equal(R.readAccum().view(np.uint32), acc.view(np.uint32))
+            assert {k: st_w[k] for k in STAT_KEYS} == {k: st[k] for k in STAT_KEYS} and st_w["diag"][8] == 0
+        R.close()
