@@ -1748,8 +1748,8 @@ __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTm
       // the plain slab test of the intersection program with the current ray.tmin (and the plain division)
       Ray rr = ray; rr.tmin = walkTmin;
       float s0, s1;
-      const bool shit = boxTest(rr, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), s0, s1);
-      if ((shit && active) != hit || (hit && (s0 != t0 || s1 != t1))) C.st[ST_KD_MISMATCH]++;
+      const bool slabHit = boxTest(rr, mk(q0.x, q0.y, q0.z), mk(q0.w, q1.x, q1.y), s0, s1);
+      if ((slabHit && active) != hit || (hit && (s0 != t0 || s1 != t1))) C.st[ST_KD_MISMATCH]++;
     }
     if (hit) {
       const int qc = w.pk.get(PK_QCOUNT);
