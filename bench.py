@@ -276,9 +276,10 @@ def main():
     ap.add_argument("--in-flight", type=int, default=int(os.environ.get("EXA_BENCH_IN_FLIGHT", "0")),
                     help="frames in flight: F > 1 renders consecutive frames with F renderer handles on F streams, so that "
                          "the tail of one frame (its longest rays) overlaps the bulk of the next; every frame is complete "
-                         "and gathered, frame k+F waits for frame k.  0 = default: 3 for every number of GPUs (one protocol "
+                         "and gathered, frame k+F waits for frame k.  0 = default: 4 for every number of GPUs (one protocol "
                          "for the whole scaling curve: on one GPU, which a frame fills anyway, it is worth about 1 %%; on a "
-                         "shard of 8 a rank's frame does not fill its GPU: 4.6 -> 2.9 ms per frame rehearsed); `latency_ms` "
+                         "shard of 8 a rank's frame does not fill its GPU: 4.08 ms with one frame at a time, 2.54 / 2.34 / 2.23 / "
+                         "2.27 with 2 / 3 / 4 / 6 in flight, rehearsed); `latency_ms` "
                          "in the line is one frame at a time")
     ap.add_argument("--spawn-check", action="store_true",
                     help="every rank prints its RANK/WORLD_SIZE/MASTER_* as one JSON line and exits (no GPU; tests)")
@@ -374,7 +375,7 @@ def main():
     rehearse = os.environ.get("EXA_BENCH_SHARD") if world == 1 else None
     shard_rank, shard_world = (int(x) for x in rehearse.split(",")) if rehearse else (rank, world)
 
-    F = args.in_flight if args.in_flight > 0 else 3          # the same protocol for every N: `value` is a throughput
+    F = args.in_flight if args.in_flight > 0 else 4          # the same protocol for every N: `value` is a throughput
     basis_form = args.basis_form if args.basis_form >= 0 else binding.DEFAULT_BASIS_FORM
 
     def make_renderer():
