@@ -659,6 +659,10 @@ def main():
                        "samples_per_frame": samples_total, "kernel_ms_max_over_ranks": float(kmax.item())},
             "latency_ms": latency_ms if latency_ms is not None else 1000.0 * elapsed / args.steps,
         }
+        if F > 1:
+            out["ms_per_step_note"] = (f"elapsed / steps with {F} frames in flight — a throughput: the tail of one frame (its longest rays, few "
+                                       "waves busy) overlaps the bulk of the next, so it can be BELOW roofline.kernel_ms, which is one lone "
+                                       "synchronous launch, and below latency_ms (one frame at a time); every frame is rendered completely")
         out["config"]["latency_ms"] = ("one frame at a time (march, gather, untile, host waits), wide march on: the figure "
                                        "comparable with a 1-GPU line" if latency_ms is not None else "= ms_per_step (one frame in flight)")
         # ---- roofline: the frame's launches against the resource that binds them.  No dense contraction on
