@@ -3,7 +3,8 @@
 # (no GPU: device ASan is not available on this pool).  Builds into a scratch directory:
 #   exaBuilder (owlexabrick_amd/host/exa_builder.cpp)          <- tests/fuzz_builder.py, 300 cell sets
 #   the oracle (oracle/exa_oracle.c, + float-cast-overflow)    <- tests/fuzz_oracle.py, fuzz_spec.py, whole frames of 3 case families
-#   the module's host preparation (csrc/exa_prep.cpp)          <- tests/fuzz_prep.py, 600 scenes (needs csrc/*.o: run make first)
+#   the module's host preparation (csrc/exa_prep.cpp) and the rope construction (csrc/exa_ropes.h)
+#                                                               <- tests/fuzz_prep.py, 600 scenes + 200 (needs csrc/*.o: run make first)
 #   the facade's file loaders (host/exa_host.cpp via exaRender --info) <- 150 random scenes written in the reference's formats
 # usage: tools/sanitize_host.sh [scratch dir]
 set -eu
@@ -17,7 +18,8 @@ gcc $SAN -fsanitize=float-cast-overflow -fno-sanitize-recover=float-cast-overflo
 CS="$ROOT/owlexabrick_amd/csrc"
 /opt/rocm/bin/hipcc $SAN -std=c++17 -fPIC -ffp-contract=off -c "$CS/exa_prep.cpp" -o "$D/exa_prep.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined -shared-libsan -o "$D/libexa_hip.so" \
-    "$CS/exa_kernels_f0.o" "$CS/exa_kernels_f1.o" "$CS/exa_kernels_f0e.o" "$CS/exa_lbvh.o" "$CS/exa_module.o" "$D/exa_prep.o" -lpthread 2>/dev/null
+    "$CS/exa_kernels_f0.o" "$CS/exa_kernels_f1.o" "$CS/exa_kernels_f0e.o" "$CS/exa_kernels_f0r.o" "$CS/exa_kernels_f1r.o" "$CS/exa_kernels_f0er.o" \
+    "$CS/exa_lbvh.o" "$CS/exa_module.o" "$D/exa_prep.o" -lpthread 2>/dev/null
 GCC_RT="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)"
 CLANG_RT=$(find /opt/rocm/lib/llvm/lib/clang -name "libclang_rt.asan-x86_64.so" | head -1)
 export ASAN_OPTIONS=detect_leaks=0
@@ -76,6 +78,15 @@ for s in range(100):
     fails += int(P.scalars().tobytes() != S.scalars().tobytes() or P.regions().tobytes() != S.regions().tobytes())
     P.close()
 print(f"host preparation with empty cells under ASan+UBSan: {fails} failed of 100")
+# ... and the leaves and links of the rope walk (csrc/exa_ropes.h through exa_prep_ropes) on 200 random scenes: boxes = domains
+import numpy as np
+for s in range(200):
+    P = binding.Prep(random_case(s, grids=(s % 2 == 0))[0].scene, num_threads=3)
+    r = P.ropes()
+    reg = P.regions()
+    fails += int(r["flags"] != 3 or not np.array_equal(r["boxes"][:len(reg), :3], reg["dom_lo"]) or not np.array_equal(r["boxes"][:len(reg), 3:], reg["dom_hi"]))
+    P.close()
+print(f"rope construction (exa_ropes.h) under ASan+UBSan: {fails} failed of 200 (cumulative)")
 sys.exit(1 if fails else 0)
 PY
 /opt/rocm/bin/hipcc $SAN -std=c++17 -shared-libsan -o "$D/exaRender" "$ROOT/owlexabrick_amd/host/exaRender.cpp" "$ROOT/owlexabrick_amd/host/exa_host.cpp" \
