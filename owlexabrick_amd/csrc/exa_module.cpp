@@ -287,7 +287,9 @@ struct ExaHipRenderer {
   int ropeFastDiv = 0, ropeAddr32 = 0;
   int walkMode = 0;
   uint32_t activeRegions = 0;        // regions active for the volume march (refreshed with the activity)
-  static constexpr double kRopeActiveFraction = 0.5;
+  // (C4 scene, kernel ms stack / rope by active fraction: 0.16 3.82 / 5.35, 0.23 5.45 / 7.22, 0.33 6.96 / 7.88, 0.50 1.91 / 1.65,
+  //  0.62 1.98 / 1.66, 0.79 2.01 / 1.68, 1.0 19.84 / 17.31; profiles/r05_experiments.txt 5)
+  static constexpr double kRopeActiveFraction = 0.4;
   bool ropeWanted() const
   {
     if (!useKd() || ropeFailed || walkMode == 1) return false;

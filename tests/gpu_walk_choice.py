@@ -33,7 +33,16 @@ TFS = {"ramp (reference default)": tf(t),
        "upper half": tf(np.where(t >= 0.5, 0.5, 0.0)),
        "upper quarter": tf(np.where(t >= 0.75, 0.5, 0.0)),
        "top 10 %": tf(np.where(t >= 0.9, 0.8, 0.0)),
-       "lower quarter": tf(np.where(t <= 0.25, 0.3, 0.0))}
+       "lower quarter": tf(np.where(t <= 0.25, 0.3, 0.0)),
+       # thin TFs: little opacity anywhere, so that rays are long and the walk is most of the frame
+       "below 0.05, thin": tf(np.where(t <= 0.05, 0.02, 0.0)),
+       "below 0.1, thin": tf(np.where(t <= 0.1, 0.02, 0.0)),
+       "below 0.15, thin": tf(np.where(t <= 0.15, 0.02, 0.0)),
+       "below 0.25, thin": tf(np.where(t <= 0.25, 0.02, 0.0)),
+       "above 0.2, thin": tf(np.where(t >= 0.2, 0.02, 0.0)),
+       "above 0.3, thin": tf(np.where(t >= 0.3, 0.02, 0.0)),
+       "above 0.4, thin": tf(np.where(t >= 0.4, 0.02, 0.0)),
+       "everything, thin": tf(np.full(128, 0.02))}
 for label, xf in TFS.items():
     for c in range(len(sc.fields)):
         R.updateXF(c, xf[:, 3], xf[:, :3], (0.0, 1.0), 1.0)
