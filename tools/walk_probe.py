@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""How coherent are the 64 kd walks of a wave?  (GPU box; diagnostic for DESIGN.md 4.1, "wave-coherent walk")
+"""How coherent are the 64 kd STACK walks of a wave?  (GPU box; diagnostic of rounds 3-4 for the stack walk, option walk = 1)
 Renders one frame of a bench configuration through the counting variant with option walk_probe = 1 and prints, per frame:
 lane node steps (sum over rays), wave-level node-step executions of the per-lane walk as shipped (with their lane
 utilisation), the size of the UNION of visited nodes per wave summed over the waves — the least number of node steps a walk
@@ -38,6 +38,7 @@ R.setSpaceSkipping(True)
 R.setGradientShadingDVR(True)
 R.updateDt(0.5)
 R.updateFrameID(0)
+R.setOption("walk", 1)                  # the probe is about the stack walk (the rope walk keeps no stack and visits 1.3 records per segment)
 R.setOption("walk_probe", 1)
 _, st = R.renderStats()
 waves = ((W + 15) // 16) * ((H + 15) // 16) * 4
