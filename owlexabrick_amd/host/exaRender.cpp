@@ -9,6 +9,7 @@
 //             [--gpus N | --devices 0,1,..]  one renderer over several GPUs (tiles dealt round-robin, stored straight into
 //                                            the first device's frame); a device may be listed more than once
 //             [--allow-empty-cells]          cell id -1 in the .bricks file = no cell (the reference's ALLOW_EMPTY_CELLS build)
+//             [--option key=int]...          exa_hip_set_option, e.g. walk=1|2 (stack / rope walk of the region kd-tree), ao_overlap=0
 //             [--pipeline]                   frames go to two device buffers in turn, frame k's copy to the host overlaps
 //                                            frame k+1's march
 #include "exa_host.h"
@@ -62,6 +63,7 @@ int main(int argc, char **argv)
     bool pipeline = false;
     bool allowEmptyCells = false;
     std::vector<float> contourPlanes;                             // 4 floats per --contourplane (normal, offset)
+    std::vector<std::pair<std::string, int>> options;             // --option key=value
     std::vector<int> contourChans;
     for (int i = 1; i < argc; i++) {
       const std::string a = argv[i];
@@ -104,6 +106,15 @@ int main(int argc, char **argv)
       }
       else if (a == "--pipeline") pipeline = true;
       else if (a == "--allow-empty-cells") allowEmptyCells = true;    // the reference built with -DALLOW_EMPTY_CELLS=1
+      else if (a == "--option") {                                     // exa_hip_set_option: --option walk=2, --option ao_overlap=0 ...
+        if (i + 1 >= argc) throw std::runtime_error("missing key=value after --option");
+        const std::string kv = argv[++i];
+        const size_t eq = kv.find('=');
+        char *end = nullptr;
+        const long v = eq == std::string::npos ? 0 : std::strtol(kv.c_str() + eq + 1, &end, 10);
+        if (eq == std::string::npos || eq == 0 || end == kv.c_str() + eq + 1 || *end) throw std::runtime_error("--option wants key=integer");
+        options.emplace_back(kv.substr(0, eq), (int)v);
+      }
       else if (a[0] != '-') cfgName = a;
       else throw std::runtime_error("unknown flag " + a);
     }
@@ -123,6 +134,7 @@ int main(int argc, char **argv)
     std::vector<uint32_t> fb(size_t(size.x) * size.y);
     if (devices.empty()) devices.push_back(0);
     Renderer renderer(config->bricks.sp, config->surfaces, config->scalarFields, devices);  // viewer.cpp:1256-1260
+    for (const auto &kv : options) renderer.setOption(kv.first, kv.second);
     if (devices.size() > 1) std::printf("devices %zu\n", devices.size());
     renderer.setVoxelSpaceTransform(config->bricks.voxelSpaceTransform);
     renderer.resizeFrameBuffer(fb.data(), size);

@@ -520,6 +520,8 @@ ExaHipStats Renderer::renderStats()
   return s;
 }
 
+void Renderer::setOption(const std::string &key, int value) { check(exa_hip_set_option(handle, key.c_str(), value), handle); }
+
 ExaHipStats Renderer::stats() const
 {
   ExaHipStats s;

@@ -179,6 +179,11 @@ struct Renderer {
   // orders its copy-out behind it on that stream and may start the next frame into another buffer meanwhile
   void renderAsync(void *deviceColorBuffer, void *hipStream);
 
+  // exa_hip_set_option (include/exa_hip.h): tuning knobs of the module that have no counterpart in the reference's
+  // interface (which walk of the region kd-tree the march takes, launch order, AO launch plan ...); none changes a picture
+  // beyond the stated float tolerance
+  void setOption(const std::string &key, int value);
+
   ExaHipStats stats() const;
   ExaHipStats renderStats();                 // the same frame through the counting variant of the kernels
   size_t numRegions = 0, numLeafEntries = 0; // what Regions::buildFrom produced (exa/Regions.cpp:308-319 prints them)

@@ -59,6 +59,28 @@ def test_exarender_flag_errors_are_reported_before_anything_runs():
     assert r.returncode == 1 and "unknown flag --bogus" in r.stderr
     r = _run(["x.exa", "--contourplane", "1", "0", "0"])
     assert r.returncode == 1 and "missing value" in r.stderr
+    for bad in (["--option", "walk"], ["--option", "=2"], ["--option", "walk=two"], ["--option"]):
+        r = _run(["x.exa"] + bad)
+        assert r.returncode == 1 and ("--option wants key=integer" in r.stderr or "missing key=value" in r.stderr), (bad, r.stderr)
+
+
+@pytest.mark.gpu
+def test_exarender_option_flag_reaches_the_module():
+    """--option key=int = exa_hip_set_option: the stack walk and the rope walk of the region kd-tree give the same file, byte
+    for byte, and --stats tells them apart (the rope walk fetches no 16-byte node per leaf); an unknown key is the module's error"""
+    sc = scenes.amr(seed=3, root=(2, 2, 2), B=4, levels=3)
+    with tempfile.TemporaryDirectory() as d:
+        cfg = scenes.write_exa(sc, d, "amr")
+        files, nodes = {}, {}
+        for walk in (1, 2):
+            out = os.path.join(d, f"w{walk}.ppm")
+            r = _run([cfg, "--size", "64", "48", "-o", out, "--frames", "2", "--stats", "--option", f"walk={walk}"])
+            assert r.returncode == 0, r.stderr
+            files[walk] = open(out, "rb").read()
+            nodes[walk] = int(r.stdout.split("nodes_visited")[1].split()[0])
+        assert files[1] == files[2] and nodes[1] != nodes[2]
+        r = _run([cfg, "--size", "64", "48", "--option", "no_such_knob=1"])
+        assert r.returncode == 1 and "unknown key no_such_knob" in r.stderr
 
 
 @pytest.mark.gpu
