@@ -832,6 +832,12 @@ def main():
                "march_headers_along_the_leaf_list": nleaf * 32,
                "kd_nodes_and_march_copy": 2 * int(prep.scene.numKdNodes) * 16,
                "region_info": int(prep.scene.numRegions) * 16}
+        if st.get("walk_leaf_visits", 0) > 0:
+            # the frame took the rope walk: 64 B per leaf (regions + gaps = empty child slots of the kd-tree) and the 16-B nodes
+            # behind the links are what it reads instead of the kd-tree's march copy
+            kdn = prep.kd_nodes()
+            gaps = int((kdn["left"] == binding.KD_EMPTY).sum() + (kdn["right"] == binding.KD_EMPTY).sum()) if len(kdn) else 0
+            res["rope_leaves_and_nodes"] = (int(prep.scene.numRegions) + gaps) * 64 + int(prep.scene.numKdNodes) * 16
         roof["hbm_resident_bytes"] = int(sum(res.values()))
         roof["hbm_resident_breakdown"] = res
         if traffic:
