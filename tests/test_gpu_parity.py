@@ -31,6 +31,17 @@ def _meshes():
     return [(np.array(v), np.array(t)), (np.array(quad_v, dtype=np.float64), np.array([[0, 1, 2], [0, 2, 3]]))]
 
 
+def _an_interior_x_plane(sc):
+    """the x-plane of the region partition that most regions share as a lower face (a face of many boxes, strictly inside the grid)"""
+    P = binding.Prep(sc)
+    reg = P.regions()
+    vals, counts = np.unique(reg["dom_lo"][:, 0], return_counts=True)
+    inner = vals > reg["dom_lo"][:, 0].min()
+    plane = float(vals[inner][np.argmax(counts[inner])])
+    P.close()
+    return plane
+
+
 CASES = {
     "ex0": lambda: Case(scenes.example("ex0"), W=96, H=64),
     "ex1_grad": lambda: Case(scenes.example("ex1"), W=96, H=64, grad=1),
@@ -81,6 +92,19 @@ CASES = {
     "amr_mesh_ao": lambda: Case(_amr(), W=64, H=64, grad=1, opacity_scale=0.05, meshes=_meshes(), ao=1, ao_length=12.0),
     "amr_inside": lambda: Case(_amr(), W=96, H=96, grad=1, camera=([20.3, 22.1, 14.2], [30, 20, 10], [0, 1, 0], 80.0)),
     "gen_exajet": lambda: Case(scenes.generated(kind="exajet", seed=11, root=(4, 2, 2), B=8, levels=3), W=160, H=96, grad=1),
+    # every ray parallel to the x-planes (direction.x exactly 0: the walks' d == 0 branches, the plain division of the rope walk),
+    # from an origin between two planes, and from one that lies exactly IN a plane of the partition (x = 8: (plane - o) / d = 0 / 0,
+    # which the reference's NaN-ignoring min / max turn into a miss of both neighbours, exabrick.cu:197-210)
+    "amr_rays_parallel_to_x_planes": lambda: Case(_amr(), W=64, H=48, grad=1, camera=dict(
+        pos=np.array([10.3, -20.0, 9.1], dtype=np.float32), dir00=np.array([0.0, 1.0, -0.12], dtype=np.float32),
+        dirDu=np.array([0.0, 0.0, 0.004], dtype=np.float32), dirDv=np.array([0.0, 0.006, 0.0], dtype=np.float32))),
+    "amr_rays_in_an_x_plane": lambda: Case(_amr(), W=64, H=48, grad=1, camera=dict(
+        pos=np.array([_an_interior_x_plane(_amr()), -20.0, 9.1], dtype=np.float32), dir00=np.array([0.0, 1.0, -0.12], dtype=np.float32),
+        dirDu=np.array([0.0, 0.0, 0.004], dtype=np.float32), dirDv=np.array([0.0, 0.006, 0.0], dtype=np.float32))),
+    # ... and a camera far away with a tiny field of view: direction components below 2^-30 (outside the short division's range)
+    "amr_far_camera_tiny_components": lambda: Case(_amr(), W=64, H=48, grad=1, camera=dict(
+        pos=np.array([24.0, 20.0, -3.0e6], dtype=np.float32), dir00=np.array([-3.0e-10, -2.0e-10, 1.0], dtype=np.float32),
+        dirDu=np.array([1.0e-11, 0.0, 0.0], dtype=np.float32), dirDv=np.array([0.0, 1.0e-11, 0.0], dtype=np.float32))),
 }
 
 
