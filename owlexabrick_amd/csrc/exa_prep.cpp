@@ -384,7 +384,7 @@ int exa_prep_ropes(const ExaPrep *P, uint64_t *numLeaves, uint64_t *numNodes, fl
     }
   exa::RopeBuild rb;
   exa::buildRopesHost(P->kdNodes.data(), P->kdNodes.size(), P->kdRoot, dom.data(), P->regions.size(), lo, hi,
-                      std::max(1u, std::thread::hardware_concurrency()), rb);
+                      std::min(16u, std::max(1u, std::thread::hardware_concurrency())), rb);
   if (!leafBoxes) { *numLeaves = rb.leaves.size(); *numNodes = rb.nodes.size(); return 0; }
   if (*numLeaves != rb.leaves.size() || *numNodes != rb.nodes.size()) { g_prepError = "exa_prep_ropes: array sizes do not match the counts"; return 1; }
   for (size_t i = 0; i < rb.leaves.size(); i++) {
