@@ -10,6 +10,10 @@
 #ifndef EXA_MARCH_WAVES
 #define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup)
 #endif
+#ifndef EXA_ROPE_WAVES
+#define EXA_ROPE_WAVES 7       // ... and its rope-walk variant in the default association of the basis sums (72 VGPRs, 22 KB of LDS
+                               // per workgroup; exa_kernels.hip: marchWaves, LEAN)
+#endif
 #ifndef EXA_MULTI_WAVES
 #define EXA_MULTI_WAVES 6      // ... and the multi-channel march (80 VGPRs; two TF tables + a 3-entry stack: 25 KB of LDS per workgroup)
 #endif
@@ -115,8 +119,9 @@ struct DeviceScene {
 #define EXA_KD_STACK_MULTI 3   // the multi-channel march: one entry fewer, so that two TF tables + stack + queue fit 6 workgroups per CU
 #endif
 #ifndef EXA_ROPE_QUEUE
-#define EXA_ROPE_QUEUE 6    // segment queue of the rope walk: it keeps no stack, so the queue gets the stack's LDS as well — six 16-byte
-                            // entries {region record, t1, first sample's t_i, t0} in the stack walk's 96 B per lane
+#define EXA_ROPE_QUEUE 5    // segment queue of the rope walk: it keeps no stack, so the queue gets the stack's LDS as well — 16-byte
+                            // entries {region record, t1, first sample's t_i, t0}.  Five of them (80 B per lane + one TF table = 22 KB
+                            // per workgroup) let seven workgroups share a CU; six entries at six waves measure the same as five
 #endif
 #ifndef EXA_ROPE_QUEUE_MULTI
 #define EXA_ROPE_QUEUE_MULTI 5   // ... with two TF tables in LDS (the multi-channel march): 80 B per lane keep six workgroups per CU

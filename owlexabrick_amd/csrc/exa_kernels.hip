@@ -116,6 +116,10 @@ template <bool FAST> __device__ __forceinline__ float fsqrt(float a) { return FA
 
 struct Ray { V3 org, dir; float tmin, tmax; };
 
+// LEAN (the variants of the march compiled for seven waves per SIMD: 72 registers): a value the compiler cannot see through, so
+// that what is computed from it is computed where it is used instead of once before the march loop and kept in a register across it
+__device__ __forceinline__ float opaque(float x) { asm volatile("" : "+v"(x)); return x; }
+
 // "does any active lane want this": the compare's lane mask tested directly (v_cmp + s_cmp); HIP's anyLane() first
 // turns the flag into a register value and compares that again
 __device__ __forceinline__ bool anyLane(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
@@ -212,11 +216,13 @@ __device__ __forceinline__ uint32_t make_rgba8(float r, float g, float b)
 // ------------------------------------------------------------------------
 template <bool FAST = false, bool HAVE_RCP = false>
 __device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameState &fs, float in_scalar, int channel,
-                                           const float fracMagic, const float rcpRange = 0.f)
+                                           const float fracMagic, const float rcpRange = 0.f, const float range = 0.f)
 {
-  // HAVE_RCP (fast_math only): rcpRange is the caller's copy of rcp((hi - lo) + 1e-20f), the value fdiv<true> computes here
+  // HAVE_RCP (fast_math only): range / rcpRange are the caller's copies of (hi - lo) + 1e-20f and of its rcp, the values
+  // fdiv<true> works out here — wave-uniform, so the caller holds them in scalar registers; formed here they sit in two
+  // vector registers across the whole march
   const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
-  float scalar = (FAST && HAVE_RCP) ? fdivExact<true>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f, rcpRange)
+  float scalar = (FAST && HAVE_RCP) ? fdivExact<true>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), range, rcpRange)
                                     : fdivExact<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
   scalar = fminf(EXA_NUM_XF_VALUES - 1.f, fmaxf(0.f, scalar + .5f));
   if (FAST) {        // scalar in [0, 127]: no clamp needed; 1/127 as a constant
@@ -412,12 +418,13 @@ __device__ __forceinline__ void addBasisFast(Ctx<STATS> &C, Basis &B, const int4
   const bool vly = (uint32_t)ly < (uint32_t)sy, vhy = hy < sy;
   const bool vlz = (uint32_t)lz < (uint32_t)sz, vhz = hz < sz;
   // clamp(l, 0, size-1) as one v_med3_i32 (sizes >= 1, so 0 <= size-1 and the median IS the clamp); the compiler
-  // cannot prove the bound order and emits v_max + v_min
-  auto med3 = [](int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
-  const int cxl = med3(lx, 0, sx - 1), cxh = min(hx, sx - 1);
-  const int cyl = med3(ly, 0, sy - 1), cyh = min(hy, sy - 1);
-  const int czl = med3(lz, 0, sz - 1), czh = min(hz, sz - 1);
-  const int bx = med3(lx, 0, max(sx - 2, 0));
+  // cannot prove the bound order and emits v_max + v_min (the 0 is the instruction's inline constant: as a "v" operand
+  // it occupied a register across the whole march)
+  auto med3 = [](int a, int c) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(c)); return r; };   // clamp(a, 0, c)
+  const int cxl = med3(lx, sx - 1), cxh = min(hx, sx - 1);
+  const int cyl = med3(ly, sy - 1), cyh = min(hy, sy - 1);
+  const int czl = med3(lz, sz - 1), czh = min(hz, sz - 1);
+  const int bx = med3(lx, max(sx - 2, 0));
   float s000, s100, s010, s110, s001, s101, s011, s111;
   {
     // (eight 4-byte loads instead of four 8-byte pair loads would save the pair base, two compares and eight
@@ -576,11 +583,11 @@ __device__ __forceinline__ void addBasisFastIl(Basis &B, float *xWV, V3 *xD, con
   const bool vlx = (uint32_t)lx < (uint32_t)sx, vhx = hx < sx;
   const bool vly = (uint32_t)ly < (uint32_t)sy, vhy = hy < sy;
   const bool vlz = (uint32_t)lz < (uint32_t)sz, vhz = hz < sz;
-  auto med3 = [](int a, int b, int c) { int r; asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
-  const int cxl = med3(lx, 0, sx - 1), cxh = min(hx, sx - 1);
-  const int cyl = med3(ly, 0, sy - 1), cyh = min(hy, sy - 1);
-  const int czl = med3(lz, 0, sz - 1), czh = min(hz, sz - 1);
-  const int bx = med3(lx, 0, max(sx - 2, 0));
+  auto med3 = [](int a, int c) { int r; asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(a), "v"(c)); return r; };   // clamp(a, 0, c)
+  const int cxl = med3(lx, sx - 1), cxh = min(hx, sx - 1);
+  const int cyl = med3(ly, sy - 1), cyh = min(hy, sy - 1);
+  const int czl = med3(lz, sz - 1), czh = min(hz, sz - 1);
+  const int bx = med3(lx, max(sx - 2, 0));
   uint32_t rowLL, rowHL, rowLH, rowHH;                      // cell index of the pair's first cell, per (y,z) row
   if (SMALL) {
     const uint32_t sxy = __umul24((uint32_t)sx, (uint32_t)sy);
@@ -744,11 +751,11 @@ __device__ __forceinline__ bool samplePoint(Ctx<STATS> &C, float &value, V3 &der
 }
 
 // the sample's colour after gradient shading and its opacity after the correction; actual_dt != 0
-template <bool FAST, int STATS, bool HAVE_RCP = false>
+template <bool FAST, int STATS, bool HAVE_RCP = false, bool LEAN = false>
 __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, float actual_dt, float cellValue, V3 gradient,
-                                              float finestLevelCellWidth, int channel, const float rcpRange = 0.f)
+                                              float finestLevelCellWidth, int channel, const float rcpRange = 0.f, const float range = 0.f)
 {
-  Color4 sample = lookupXF<FAST, HAVE_RCP>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic, rcpRange);
+  Color4 sample = lookupXF<FAST, HAVE_RCP>(C.xfLds, C.a->fs, cellValue, channel, C.a->tfFracMagic, rcpRange, range);
   // the reference compares with `int finestLevelCellWidth` * 1e-6f (exabrick.cu:1124,1001); the width is an
   // integer-valued float (a power of two >= 1, checked at scene creation), so the int round trip is the identity
   if (FAST) {
@@ -759,7 +766,9 @@ __device__ __forceinline__ Color4 shadeSample(Ctx<STATS> &C, const Ray &ray, flo
     const float thr = finestLevelCellWidth * 1e-6f;
     if (g2 > thr * thr) {
       const V3 lightDir = -ray.dir;
-      const float scale = fabsf(dotF(lightDir, gradient)) * __builtin_amdgcn_rsqf(g2 * dotF(lightDir, lightDir));
+      V3 l2 = lightDir;
+      if (LEAN) l2.x = opaque(l2.x);                // |dir|^2 formed here (3 instructions) instead of kept across the march
+      const float scale = fabsf(dotF(lightDir, gradient)) * __builtin_amdgcn_rsqf(g2 * dotF(l2, l2));
       sample.x *= scale; sample.y *= scale; sample.z *= scale;
     }
   } else if (fsqrt<FAST>(dotF(gradient, gradient)) > finestLevelCellWidth * 1e-6f) {
@@ -792,13 +801,13 @@ __device__ __forceinline__ void compositeSample(Color4 &pixelColor, const Color4
 }
 
 // exabrick.cu:988-1016 integrateVolume
-template <bool FAST, int STATS, bool HAVE_RCP = false>
+template <bool FAST, int STATS, bool HAVE_RCP = false, bool LEAN = false>
 __device__ __forceinline__ void integrateVolume(Ctx<STATS> &C, const Ray &ray, Color4 &pixelColor, float actual_dt,
                                                 float cellValue, V3 gradient, float finestLevelCellWidth, int channel,
-                                                const float rcpRange = 0.f)
+                                                const float rcpRange = 0.f, const float range = 0.f)
 {
   if (actual_dt == 0.f) return;
-  const Color4 sample = shadeSample<FAST, STATS, HAVE_RCP>(C, ray, actual_dt, cellValue, gradient, finestLevelCellWidth, channel, rcpRange);
+  const Color4 sample = shadeSample<FAST, STATS, HAVE_RCP, LEAN>(C, ray, actual_dt, cellValue, gradient, finestLevelCellWidth, channel, rcpRange, range);
   compositeSample(pixelColor, sample);
 }
 
@@ -1709,9 +1718,9 @@ __device__ __forceinline__ bool ropeRayInRange(const Ray &ray)
 // one step of the rope walk: the leaf stage (slab test, accept, leave through the exit face) and then, for a lane whose
 // link names an inner node, one level of the descent — so that a lane that has just taken a link also takes the next node
 // in the same call, as kdStep does.  QN: entries of the lane's segment queue.
-// (The refined reciprocals are formed again at every step: kept in three registers across the march they cost the 80-register
-// kernel spills, and a step runs once per ~8 march iterations.)
-template <int STATS, bool SMALL, int QN>
+// (The source forms the refined reciprocals at every step; the compiler hoists them out of the march loop into three registers
+// where the register budget allows — the 80-register variants — and LEAN keeps it from doing so.)
+template <int STATS, bool SMALL, int QN, bool LEAN>
 __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a, float4 *queue,
                                          const Ray &ray, const bool fast, const float samplingOffset)
 {
@@ -1728,7 +1737,8 @@ __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTm
     // exabrick.cu:197-210 on this leaf's box (lo = q0.xyz, hi = q0.w, q1.xy)
     float lx, hx, ly, hy, lz, hz;
     if (fast) {
-      const V3 rcpDir = mk(refinedRcp(dx), refinedRcp(dy), refinedRcp(dz));
+      const V3 rcpDir = LEAN ? mk(refinedRcp(opaque(dx)), refinedRcp(opaque(dy)), refinedRcp(opaque(dz)))
+                                 : mk(refinedRcp(dx), refinedRcp(dy), refinedRcp(dz));
       lx = divByRcp(q0.x - ox, dx, rcpDir.x); hx = divByRcp(q0.w - ox, dx, rcpDir.x);
       ly = divByRcp(q0.y - oy, dy, rcpDir.y); hy = divByRcp(q1.x - oy, dy, rcpDir.y);
       lz = divByRcp(q0.z - oz, dz, rcpDir.z); hz = divByRcp(q1.y - oz, dz, rcpDir.z);
@@ -1790,7 +1800,7 @@ __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTm
     d = axis == 2 ? dz : d;
     bool goRight;                                                // right = upper side of the plane
     if (fast) {
-      const float ts = divByRcp(split - o, d, refinedRcp(d));
+      const float ts = divByRcp(split - o, d, refinedRcp(LEAN ? opaque(d) : d));
       goRight = (ts <= w.tn) == (d > 0.f);                       // far child when the plane lies at or before the entry distance
     } else if (d == 0.f) {
       goRight = !(o < split);                                    // parallel to the plane: the side that holds the origin
@@ -2238,9 +2248,22 @@ __global__ __launch_bounds__(kKdBlock, (ISO_ONLY ? EXA_AO_ISO_WAVES : EXA_PREPAS
 // NCH: 0 = cell values field by field (the ABI's layout; one channel, or the channels one after the other);
 //      2..4 = that many primary channels from the channel-interleaved copy, all of them per brick visit (addBasisFastIl)
 // ROPE: the walk is the rope walk (ropeStep) instead of the stack walk (kdStep); everything behind the segment queue is the same
-template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL, int NCH = 0, bool ROPE = false>
-__global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL34_WAVES) : (MULTI == 1 ? EXA_MULTI_WAVES : (MULTI ? 5 : EXA_MARCH_WAVES)))) void renderFrameKdKernel(const RenderArgs a)
+// waves per SIMD a variant of the march is compiled for.  Seven for the one-channel rope march (72 registers, no scratch; a
+// queue of five entries lets seven workgroups share a CU's LDS): C4 17.28 -> 17.08 ms, inside camera 22.60 -> 22.01, C5 1075 ->
+// 1068 ms per 16 samples.  Not for the instrumented variants and the source-order sums (form 0: more values in flight per
+// visit — the pixel's colour would live in scratch), nor for fields beyond 4 GiB (SMALL = false: no scratch either, but that
+// frame is heavy on HBM traffic already and a seventh wave costs it 2 %: 26.47 -> 27.04 ms).
+constexpr int marchWaves(int MULTI, int STATS, bool SMALL, int NCH, bool ROPE)
 {
+  return NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL34_WAVES)
+             : (MULTI == 1 ? EXA_MULTI_WAVES
+                           : (MULTI ? 5 : ((ROPE && !STATS && SMALL && EXA_BASIS_FORM == 1) ? EXA_ROPE_WAVES : EXA_MARCH_WAVES)));
+}
+
+template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL, int NCH = 0, bool ROPE = false>
+__global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE)) void renderFrameKdKernel(const RenderArgs a)
+{
+  constexpr bool LEAN = marchWaves(MULTI, STATS, SMALL, NCH, ROPE) >= 7;
   static_assert(NCH == 0 || (MULTI == 2 && STATS == 0), "the interleaved march is a multi-channel variant of the shipped kernel");
   // Entries of the lane's short stack.  The two-table multi-channel march runs with one fewer: a workgroup then needs
   // 25 KB instead of 28 KB of LDS and a sixth workgroup fits a CU (C3: 30.8 -> 29.4 ms; a shorter stack alone costs ~1 %:
@@ -2368,16 +2391,18 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
     const float *field = field0;
     // fast_math, one channel: the reciprocal of the TF range is the same for every sample of the frame; it is
     // wave-uniform, so it lives in a scalar register (readfirstlane) instead of a vector register
-    float xfRcpRange0 = 0.f;
-    if (FAST && !MULTI)
-      xfRcpRange0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
-                        __builtin_amdgcn_rcpf((fs.xfDomain[0][1] - fs.xfDomain[0][0]) + 1e-20f))));
+    float xfRcpRange0 = 0.f, xfRange0 = 0.f;
+    if (FAST && !MULTI) {
+      xfRange0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((fs.xfDomain[0][1] - fs.xfDomain[0][0]) + 1e-20f)));
+      xfRcpRange0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__builtin_amdgcn_rcpf(xfRange0))));
+    }
     // ... and with the interleaved march one per channel (a transcendental per channel and sample otherwise)
-    float xfRcpRangeN[NCH ? NCH : 1];
+    float xfRcpRangeN[NCH ? NCH : 1], xfRangeN[NCH ? NCH : 1];
 #pragma unroll
-    for (int c = 0; c < (NCH ? NCH : 1); c++)
-      xfRcpRangeN[c] = (FAST && NCH) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(
-                           __builtin_amdgcn_rcpf((fs.xfDomain[c][1] - fs.xfDomain[c][0]) + 1e-20f)))) : 0.f;
+    for (int c = 0; c < (NCH ? NCH : 1); c++) {
+      xfRangeN[c] = (FAST && NCH) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((fs.xfDomain[c][1] - fs.xfDomain[c][0]) + 1e-20f))) : 0.f;
+      xfRcpRangeN[c] = (FAST && NCH) ? __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__builtin_amdgcn_rcpf(xfRangeN[c])))) : 0.f;
+    }
 
     unsigned iter = 0;
     for (;; iter++) {
@@ -2391,7 +2416,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         do {
           const bool want = w.pk.get(PK_QCOUNT) < QN && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
           if (want) {
-            if (ROPE) ropeStep<STATS, SMALL, QN>(C, w, walkTmin, a, queue4, ray, ropeFast, interleavedSamplingOffset);
+            if (ROPE) ropeStep<STATS, SMALL, QN, LEAN>(C, w, walkTmin, a, queue4, ray, ropeFast, interleavedSamplingOffset);
             else kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
           }
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
@@ -2484,7 +2509,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
             const float cellValue = fdivExact<FAST>(wv, B.sumW);
             V3 grad = mk(0.f, 0.f, 0.f);
             if (GRAD) grad = gradOf(B.sumW, wv, sd, B.sumDC);
-            integrateVolume<FAST, STATS, FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, c, xfRcpRangeN[c]);
+            integrateVolume<FAST, STATS, FAST>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, c, xfRcpRangeN[c], xfRangeN[c]);
           }
         }
 #pragma unroll
@@ -2494,7 +2519,7 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
         const float cellValue = fdivExact<FAST>(B.sumWV, B.sumW);
         V3 grad = mk(0.f, 0.f, 0.f);
         if (GRAD) grad = gradOf(B.sumW, B.sumWV, B.sumD, B.sumDC);
-        integrateVolume<FAST, STATS, (FAST && !MULTI)>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, MULTI ? chan : 0, xfRcpRange0);
+        integrateVolume<FAST, STATS, (FAST && !MULTI), LEAN>(C, ray, pixelColor, actual_dt, cellValue, grad, flcw, MULTI ? chan : 0, xfRcpRange0, xfRange0);
       }
       B.sumWV = 0.f; B.sumW = 0.f; B.sumD = mk(0.f, 0.f, 0.f); B.sumDC = mk(0.f, 0.f, 0.f);
       child = 0;
@@ -2531,17 +2556,18 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
 
     C.lap(ST_T_OTHER);
     marchIters = iter;
-    // The pixel's framebuffer slot is worked out again from the thread id instead of being kept in two registers
-    // across the march (the kernel runs at exactly 80 VGPRs; the asm keeps the compiler from re-using the value
-    // computed before the loop).
+    // The pixel's framebuffer slot is worked out again from the thread id (and, in a shard, the tile number fetched again)
+    // instead of being kept in registers across the march (the kernel runs at exactly 80 — the seven-wave variant: 72 —
+    // VGPRs; the asm keeps the compiler from re-using the values computed before the loop).
     size_t slot, colorSlot;               // colorSlot: row-major in the root's frame for a device of a multi-device handle
     {
-      unsigned tid = threadIdx.x;
+      unsigned tid = threadIdx.x, bid = blockIdx.x;
       asm volatile("" : "+v"(tid));
+      asm volatile("" : "+s"(bid));
       const int lane2 = tid & 63, wave2 = (tid >> 6) & 3;
       const int inX2 = ((wave2 & 1) << 3) + laneX(lane2), inY2 = ((wave2 >> 1) << 3) + laneY(lane2);
       slot = (a.world == 1) ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2)
-                            : size_t(tile / a.world) * kTilePixels + (inY2 * kTile + inX2);
+                            : size_t(a.tileMap[(bid * wavesPerBlock + (tid >> 6)) >> 2] / a.world) * kTilePixels + (inY2 * kTile + inX2);
       colorSlot = a.colorRowMajor ? size_t(tx * kTile + inX2) + size_t(a.W) * (ty * kTile + inY2) : slot;
     }
     if (SURF && a.pixOut) {
@@ -2570,7 +2596,12 @@ __global__ __launch_bounds__(kKdBlock, (NCH ? (NCH == 2 ? EXA_IL2_WAVES : EXA_IL
     // launch-order feedback: the longest ray of this tile, in brick visits (= march iterations of its lane)
     unsigned v = marchIters;
     for (int off = 32; off > 0; off >>= 1) v = max(v, (unsigned)__shfl_down((int)v, off, 64));
-    if (lane == 0) atomicMax(&a.tileCost[tile], v);
+    // (the tile number is fetched again: the compiler copies the first fetch into a vector register — the index of this access —
+    // before the march and carries — at 72 registers: spills — it across)
+    unsigned bid = blockIdx.x, tid = threadIdx.x;
+    asm volatile("" : "+s"(bid));
+    asm volatile("" : "+v"(tid));
+    if (lane == 0) atomicMax(&a.tileCost[a.tileMap[(bid * wavesPerBlock + (tid >> 6)) >> 2]], v);
   }
   if (C.guardTripped) atomicExch(a.errorFlag, 1);
   if (STATS == 2) {
