@@ -320,7 +320,7 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * 4-entry short stack in LDS (restart from the root when an entry was dropped), which skips subtrees without an active
  * region; 2 = the rope walk: every leaf carries its box and one link per face to its neighbour (64 B per leaf, built on
  * the host at the first frame that uses it), the ray goes from leaf to leaf, the reference's slab test is evaluated on
- * each leaf's own box, no stack and no restarts — and the LDS of the stack goes to a segment queue of six 16-byte entries
+ * each leaf's own box, no stack and no restarts — and the LDS of the stack goes to a segment queue of five 16-byte entries
  * (region record, t1, the first sample's t_i, t0) instead of four 12-byte ones; inactive leaves are passed through one by one; 0 (default) = per frame: the rope walk when at least 40 % of the
  * regions are active for the volume march, else the stack walk.  Same segments, same pixels either way.
  * "basis_form" selects the association of the eight-corner sums of addBasisFunctions (programs/exabrick.cu:620-777):

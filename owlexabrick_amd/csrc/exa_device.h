@@ -8,7 +8,7 @@
 
 // ---- build-time constants shared by the module and the kernels ----
 #ifndef EXA_MARCH_WAVES
-#define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup)
+#define EXA_MARCH_WAVES 6      // waves per SIMD the one-channel march is compiled for (80 VGPRs, 26 KB of LDS per workgroup with the stack walk) ...
 #endif
 #ifndef EXA_ROPE_WAVES
 #define EXA_ROPE_WAVES 7       // ... and its rope-walk variant in the default association of the basis sums (72 VGPRs, 22 KB of LDS

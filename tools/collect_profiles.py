@@ -31,6 +31,6 @@ for src, dst in ((f"{tag}_z_pmc_c4/summary.txt", f"{tag}_final_pmc_summary.txt")
     if os.path.exists(os.path.join(O, src)):
         shutil.copy(os.path.join(O, src), os.path.join(P, dst))
 stats = glob.glob(os.path.join(O, f"{tag}_z_tl_c4", "trace", "**", "*kernel_stats.csv"), recursive=True)
-if stats:
-    shutil.copy(stats[0], os.path.join(P, f"{tag}_kernel_stats.csv"))
+if stats:          # gpurun_out/ is merged across sessions: the newest trace is this session's
+    shutil.copy(max(stats, key=os.path.getmtime), os.path.join(P, f"{tag}_kernel_stats.csv"))
 print("copied", sorted(f for f in os.listdir(P) if f.startswith(tag)))
