@@ -307,10 +307,10 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * throughput), 0 = the whole pre-pass in front of the whole march; "ao_defer" 1 (default) = the ambient-occlusion rays of the shaded hits are traced by a launch of their own,
  * one ray per lane over a compact list of the hits, 2 = as 1 with the listed rays sorted on the device by (32x32-pixel block of the
  * hit | direction class: octant x dominant axis) before they are traced, so that a wave's 64 rays start close together and head
- * the same way (counting sort: histogram, scan, scatter; hit flags combined per hit by a last kernel), 0 = inline behind each pixel's primary ray (1 is the default); "ao_overlap" 1 (default) = the deferred AO rays run on a side
+ * the same way (counting sort: histogram, scan, scatter; hit flags combined per hit by a last kernel), 0 = inline behind each pixel's primary ray (1 is the default); "ao_overlap" 1 = the deferred AO rays run on a side
  * stream BESIDE the march instead of in front of it: the march needs the surfaces' hit distance up front but their colour only for
  * its last operation, so it stores its pixel colour and a small kernel finishes the pixels (over the surfaces' colour, accumulation,
- * sRGB, pack: the same operations in the same order) once both are done, 0 = pre-pass, AO rays, march one after the other; "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
+ * sRGB, pack: the same operations in the same order) once both are done, 0 (default: the faster one with several frames in flight) = pre-pass, AO rays, march one after the other; "stats_mode" = what exa_hip_render_stats collects: 1 (default) the
  * work counters, 2 only phase_cycles, from the shipped code plus a clock read at every phase change; "walk_probe" 1 = the
  * counting variant also records every wave's SET of visited kd nodes (128 KiB of device memory per wave) and reports its
  * size summed over the waves as walk_union_nodes (a diagnostic of how coherent the 64 walks of a wave are);

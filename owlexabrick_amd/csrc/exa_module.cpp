@@ -365,12 +365,14 @@ struct ExaHipRenderer {
   hipStream_t side4 = nullptr, side2 = nullptr, sideN = nullptr;
   hipEvent_t evFork = nullptr, evJoin4 = nullptr, evJoin2 = nullptr, evJoinN = nullptr;
   DevBuf<uint32_t> surfRnd;
-  // option ao_overlap (default 1): the deferred AO rays run BESIDE the march instead of in front of it.  The march needs the
+  // option ao_overlap (default 0): 1 = the deferred AO rays run BESIDE the march instead of in front of it.  The march needs the
   // surfaces' hit distance up front but their colour only for its very last operation, and the AO launch — as long as its
   // longest rays, with few waves busy — writes nothing but that colour: the march stores its pixel colour (pixBuf) and a small
-  // kernel finishes the pixels once both are done.  Same operations per pixel, same order.
+  // kernel finishes the pixels once both are done.  Same operations per pixel, same order.  Measured on C5: -0.6 % beside the
+  // six-wave march (1079.9 -> 1073.5 ms), +1.4 % beside the seven-wave march with four frames in flight (1052 -> 1067 ms; a
+  // lone frame: 1049 / 1050) — the march now fills the GPU on its own and the finishing pass is extra traffic —, hence off.
   DevBuf<float4> pixBuf;
-  int aoOverlap = 1;
+  int aoOverlap = 0;
   hipEvent_t evPre = nullptr, evPre2 = nullptr, evAo = nullptr, evAo2 = nullptr;
   DevBuf<AoRecord> aoRecs;              // deferred AO rays: one record per shaded hit and pixel slot at most
   DevBuf<uint32_t> aoCount;             // [0..3] the frame's list (or the cheap pipeline's), [4..7] the heavy pipeline's

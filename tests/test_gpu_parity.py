@@ -227,6 +227,22 @@ def test_ao_rays_match_up_to_trig_ulps():
     assert o[1][..., :3].sum() > 0
 
 
+@pytest.mark.parametrize("accel", [1, 2], ids=["kd", "rope"])
+def test_ao_rays_beside_the_march_change_no_pixel(accel):
+    # option ao_overlap: the AO launch in front of the march (0, the default) or on a side stream beside it, the pixels finished by
+    # compositeKdKernel (1); deferred (ao_defer 1, default), sorted (2) or inline (0) rays: one frame, bit for bit, over 3 samples
+    case = Case(_amr(), W=96, H=80, grad=1, iso=[(0.45, 0)], ao=1, ao_length=6.0)
+    frames = {}
+    for plan in ((0, 1), (1, 1), (1, 2), (0, 0)):
+        # options are applied in order, after the walk the case's `accel` selects (tests/common.py)
+        case.options = {"accel": 1, "walk": 1 if accel == 1 else 2, "ao_overlap": plan[0], "ao_defer": plan[1]}
+        frames[plan] = case.run_hip(frames=3)
+    ref = frames[(0, 1)]
+    assert ref[1][..., :3].sum() > 0
+    for plan, f in frames.items():
+        assert np.array_equal(f[0], ref[0]) and np.array_equal(f[1].view(np.uint32), ref[1].view(np.uint32)), plan
+
+
 @pytest.mark.parametrize("name", sorted(GOLDEN_CASES))
 def test_hip_matches_golden_fixture(name):
     g = np.load(os.path.join(ROOT, "tests", "golden", f"oracle_{name}.npz"))
