@@ -219,8 +219,7 @@ __device__ __forceinline__ Color4 lookupXF(const float4 *xf, const ExaHipFrameSt
                                            const float fracMagic, const float rcpRange = 0.f, const float range = 0.f)
 {
   // HAVE_RCP (fast_math only): range / rcpRange are the caller's copies of (hi - lo) + 1e-20f and of its rcp, the values
-  // fdiv<true> works out here — wave-uniform, so the caller holds them in scalar registers; formed here they sit in two
-  // vector registers across the whole march
+  // fdiv<true> works out here — wave-uniform and the same for every sample of the frame, formed once by the caller
   const float lo = fs.xfDomain[channel][0], hi = fs.xfDomain[channel][1];
   float scalar = (FAST && HAVE_RCP) ? fdivExact<true>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), range, rcpRange)
                                     : fdivExact<FAST>((EXA_NUM_XF_VALUES - 1) * (in_scalar - lo), (hi - lo) + 1e-20f);
@@ -1720,7 +1719,7 @@ __device__ __forceinline__ bool ropeRayInRange(const Ray &ray)
 // in the same call, as kdStep does.  QN: entries of the lane's segment queue.
 // (The source forms the refined reciprocals at every step; the compiler hoists them out of the march loop into three registers
 // where the register budget allows — the 80-register variants — and LEAN keeps it from doing so.)
-template <int STATS, bool SMALL, int QN, bool LEAN>
+template <int STATS, bool SMALL, int QN, bool LEAN, bool PACKED>
 __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a, float4 *queue,
                                          const Ray &ray, const bool fast, const float samplingOffset)
 {
@@ -1770,13 +1769,13 @@ __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTm
       // (exabrick.cu:1141-1144), which is worked out HERE, where most lanes of the wave are busy, instead of at the pop,
       // which runs in nearly every march iteration for a handful of lanes
       float t_i = 0.f;
-      if (a.leafBeginBits) {
+      if (PACKED) {
         const uint32_t level = __float_as_uint(q1.z) >> (a.leafBeginBits + a.leafSizeBits);
         const float flcw = __int_as_float((127 + (int)level) << 23);                       // 2^level
         if (a.invDtPow2 != 0.f) t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float((127 - (int)level) << 23), samplingOffset);
         else t_i = firstSampleT(t0, a.p.dt * flcw, samplingOffset);
       }
-      queue[slot * kKdBlock] = make_float4(a.leafBeginBits ? q1.z : __int_as_float(r3.z), t1, t_i, t0);
+      queue[slot * kKdBlock] = make_float4(PACKED ? q1.z : __int_as_float(r3.z), t1, t_i, t0);
       w.pk.inc(PK_QCOUNT);
       walkTmin = t1 * (1.0000001f);                              // exabrick.cu:1698
     }
@@ -2264,6 +2263,10 @@ template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL, int
 __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE)) void renderFrameKdKernel(const RenderArgs a)
 {
   constexpr bool LEAN = marchWaves(MULTI, STATS, SMALL, NCH, ROPE) >= 7;
+  // The rope march takes the region's packed record from the leaf (the module launches it only for scenes whose records pack),
+  // its counting variant the region id: known when the kernel is compiled.  The stack walk finds out from its arguments.
+  constexpr bool ROPE_PACKED = ROPE && STATS != 1;
+  const bool packedRec = ROPE ? ROPE_PACKED : a.leafBeginBits != 0;
   static_assert(NCH == 0 || (MULTI == 2 && STATS == 0), "the interleaved march is a multi-channel variant of the shipped kernel");
   // Entries of the lane's short stack.  The two-table multi-channel march runs with one fewer: a workgroup then needs
   // 25 KB instead of 28 KB of LDS and a sixth workgroup fits a CU (C3: 30.8 -> 29.4 ms; a shorter stack alone costs ~1 %:
@@ -2393,6 +2396,8 @@ __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE
     // wave-uniform, so it lives in a scalar register (readfirstlane) instead of a vector register
     float xfRcpRange0 = 0.f, xfRange0 = 0.f;
     if (FAST && !MULTI) {
+      // (the compiler folds this readfirstlane of a provably uniform value away and keeps the range in a vector register after all;
+      // forcing the scalar register with an asm v_readfirstlane measured the same, 17.03-17.11 against 16.98-17.03 ms)
       xfRange0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int((fs.xfDomain[0][1] - fs.xfDomain[0][0]) + 1e-20f)));
       xfRcpRange0 = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(__builtin_amdgcn_rcpf(xfRange0))));
     }
@@ -2416,7 +2421,7 @@ __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE
         do {
           const bool want = w.pk.get(PK_QCOUNT) < QN && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
           if (want) {
-            if (ROPE) ropeStep<STATS, SMALL, QN, LEAN>(C, w, walkTmin, a, queue4, ray, ropeFast, interleavedSamplingOffset);
+            if (ROPE) ropeStep<STATS, SMALL, QN, LEAN, ROPE_PACKED>(C, w, walkTmin, a, queue4, ray, ropeFast, interleavedSamplingOffset);
             else kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
           }
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
@@ -2439,7 +2444,7 @@ __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE
         }
         w.pk.template incWrap<QN>(PK_QHEAD);
         w.pk.dec(PK_QCOUNT);
-        if (a.leafBeginBits) {
+        if (packedRec) {
           // the leaf reference of the march tree is the region's record itself: no load between the queue and
           // the first brick record
           const unsigned d = (unsigned)region;
@@ -2454,7 +2459,7 @@ __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE
         C.count(ST_SEGMENTS);
         haveSeg = true;
         w.pk.setBit(PK_NEEDHDR);
-        if (ROPE && a.leafBeginBits)                              // the walk has worked it out with the leaf (ropeStep)
+        if (ROPE_PACKED)                                          // the walk has worked it out with the leaf (ropeStep)
           t_i = tiQueued;
         else if (a.invDtPow2 != 0.f)                              // :1141-1144
           t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float(0x7f000000 - __float_as_int(flcw)), interleavedSamplingOffset);

@@ -292,7 +292,8 @@ struct ExaHipRenderer {
   static constexpr double kRopeActiveFraction = 0.4;
   bool ropeWanted() const
   {
-    if (!useKd() || ropeFailed || walkMode == 1) return false;
+    // (the rope march reads the region's packed record from the leaf: scenes whose records do not pack keep the stack walk)
+    if (!useKd() || ropeFailed || walkMode == 1 || leafBeginBits == 0) return false;
     if (walkMode == 2) return true;
     return double(activeRegions) >= kRopeActiveFraction * double(sc.numRegions);
   }
