@@ -292,7 +292,9 @@ int exa_hip_read_activity(ExaHipRenderer *, int32_t which /*0 volume, 1 iso*/, u
  * a DVR march of 2..4 primary channels reads a channel-interleaved copy float[cell][channel] of those fields (built on
  * the device at the first such frame) and evaluates all channels per brick visit, 0 = field by field from the arrays
  * as uploaded; "addr64" 1 = the march forms 64-bit cell / header / node addresses even where a scene is small enough for
- * 32-bit offsets from a uniform base (default 0: chosen per scene; tests); "brick_order" 0 = the bricks' cells lie in
+ * 32-bit offsets from a uniform base (default 0: chosen per scene; "pack_records" 0 = the march takes region ids from the walk and loads the region
+ * records, as it does in scenes whose records {first brick, brick count, level} do not fit the 32 bits of a leaf reference (default 1:
+ * packed where they fit; tests); tests); "brick_order" 0 = the bricks' cells lie in
  * memory in the order of the brick list (the running `begin` of OptixRenderer.cpp:71-93), 1 = along a Morton curve of the
  * brick centres (re-laid on the device at the next frame; cells are only found through their brick's `begin`, so pixels
  * cannot change; environment EXA_BRICK_ORDER sets the initial value); "tile_feedback" 1 (default) = after a

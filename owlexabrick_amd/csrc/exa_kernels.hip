@@ -1719,11 +1719,12 @@ __device__ __forceinline__ bool ropeRayInRange(const Ray &ray)
 // in the same call, as kdStep does.  QN: entries of the lane's segment queue.
 // (The source forms the refined reciprocals at every step; the compiler hoists them out of the march loop into three registers
 // where the register budget allows — the 80-register variants — and LEAN keeps it from doing so.)
-template <int STATS, bool SMALL, int QN, bool LEAN, bool PACKED>
+template <int STATS, bool SMALL, int QN, bool LEAN, int PACKED_CT /* 1 / 0: known when compiled, -1: a.leafBeginBits says */>
 __device__ __forceinline__ void ropeStep(Ctx<STATS> &C, KdWalk &w, float &walkTmin, const RenderArgs &a, float4 *queue,
                                          const Ray &ray, const bool fast, const float samplingOffset)
 {
   const float ox = ray.org.x, oy = ray.org.y, oz = ray.org.z, dx = ray.dir.x, dy = ray.dir.y, dz = ray.dir.z;
+  const bool PACKED = PACKED_CT < 0 ? a.leafBeginBits != 0 : PACKED_CT != 0;
   if (w.ref < 0 && w.ref != EXA_KD_DONE) {
     C.phase(ST_W_LEAF);
     C.count(ST_NODES, 4);
@@ -2263,10 +2264,12 @@ template <bool GRAD, bool FAST, int MULTI, bool SURF, int STATS, bool SMALL, int
 __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE)) void renderFrameKdKernel(const RenderArgs a)
 {
   constexpr bool LEAN = marchWaves(MULTI, STATS, SMALL, NCH, ROPE) >= 7;
-  // The rope march takes the region's packed record from the leaf (the module launches it only for scenes whose records pack),
-  // its counting variant the region id: known when the kernel is compiled.  The stack walk finds out from its arguments.
-  constexpr bool ROPE_PACKED = ROPE && STATS != 1;
-  const bool packedRec = ROPE ? ROPE_PACKED : a.leafBeginBits != 0;
+  // Does the queue hand over the region's packed record (the march tree's leaf reference) or its id?  The 32-bit variants of the
+  // rope march are launched only for scenes whose records pack (launchRenderKdT: `small`), its counting variant takes ids: known
+  // when the kernel is compiled (no test of a kernel argument in the pop and at the leaf: C4 17.11 -> 17.03 ms).  Everything else
+  // finds out from its arguments.
+  constexpr int PACKED_CT = !ROPE ? -1 : (STATS == 1 ? 0 : (SMALL ? 1 : -1));
+  const bool packedRec = PACKED_CT < 0 ? a.leafBeginBits != 0 : PACKED_CT != 0;
   static_assert(NCH == 0 || (MULTI == 2 && STATS == 0), "the interleaved march is a multi-channel variant of the shipped kernel");
   // Entries of the lane's short stack.  The two-table multi-channel march runs with one fewer: a workgroup then needs
   // 25 KB instead of 28 KB of LDS and a sixth workgroup fits a CU (C3: 30.8 -> 29.4 ms; a shorter stack alone costs ~1 %:
@@ -2421,7 +2424,7 @@ __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE
         do {
           const bool want = w.pk.get(PK_QCOUNT) < QN && w.ref != EXA_KD_DONE;   // top-ups matter: only lanes with <= 2 / 1 / 0 queued: 23.3 / 25.8 / 34.2 ms
           if (want) {
-            if (ROPE) ropeStep<STATS, SMALL, QN, LEAN, ROPE_PACKED>(C, w, walkTmin, a, queue4, ray, ropeFast, interleavedSamplingOffset);
+            if (ROPE) ropeStep<STATS, SMALL, QN, LEAN, PACKED_CT>(C, w, walkTmin, a, queue4, ray, ropeFast, interleavedSamplingOffset);
             else kdStep<false, STATS, SMALL, KS>(C, w, walkTmin, a, stackF, qRegion, qT, ray, 0, walkTmin, 1.f, a.kdMarchNodes, a.kdMarchRoot);
           }
         } while (anyLane(!haveSeg && w.pk.get(PK_QCOUNT) == 0 && w.ref != EXA_KD_DONE));
@@ -2459,7 +2462,7 @@ __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE
         C.count(ST_SEGMENTS);
         haveSeg = true;
         w.pk.setBit(PK_NEEDHDR);
-        if (ROPE_PACKED)                                          // the walk has worked it out with the leaf (ropeStep)
+        if (ROPE && packedRec)                                    // the walk has worked it out with the leaf (ropeStep)
           t_i = tiQueued;
         else if (a.invDtPow2 != 0.f)                              // :1141-1144
           t_i = firstSampleTPow2(t0, a.p.dt * flcw, a.invDtPow2 * __int_as_float(0x7f000000 - __float_as_int(flcw)), interleavedSamplingOffset);
@@ -3112,7 +3115,8 @@ static hipError_t launchRenderKdT(const RenderArgs &a, int numBlocks, bool grad,
   const size_t lds = size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4) + perLane * kKdBlock + EXA_LDS_PAD;
   const dim3 grid(numBlocks * (256 / kKdBlock)), block(kKdBlock);
   // the instrumented variants keep the general address arithmetic (fewer instantiations)
-  const bool small = a.mul24 && a.addr32 && (!ROPE || a.ropeAddr32);
+  // (the 32-bit rope variants also take for granted that the region records pack: see renderFrameKdKernel, PACKED_CT)
+  const bool small = a.mul24 && a.addr32 && (!ROPE || (a.ropeAddr32 && a.leafBeginBits));
 #define EXA_LAUNCH(G, F, M, I, S, A) hipLaunchKernelGGL((renderFrameKdKernel<G, F, M, I, S, A, 0, ROPE>), grid, block, lds, s, a)
 #define EXA_PICK2(G, F, M, I) do { if (stats == 1) EXA_LAUNCH(G, F, (M ? 2 : 0), I, 1, false); else if (stats == 2) EXA_LAUNCH(G, F, (M ? 2 : 0), I, 2, false); \
                                    else if (small) EXA_LAUNCH(G, F, M, I, 0, true); else EXA_LAUNCH(G, F, M, I, 0, false); } while (0)

@@ -227,6 +227,8 @@ struct ExaHipRenderer {
  bool emptyCells = false;           // the scene is marked allowEmptyCells (the reference's ALLOW_EMPTY_CELLS build): source-order kernels with the poison test
   int basisForm = 1;                 // option "basis_form": 1 (default) = the eight-corner basis sums per axis with fused multiply-adds, 0 = in the reference's source order
   int addr64 = 0;                    // option "addr64": the general 64-bit address form even where 32-bit offsets would do (tests)
+  int packRecords = 1;               // option "pack_records": 0 = the march takes region ids and loads the region records, as in scenes
+                                     // whose records {first brick, brick count, level} do not fit the 32 bits of a leaf reference (tests)
   uint64_t totalCells = 0;
   // Order of the bricks' cells in memory (option brick_order): 0 = as uploaded (the running `begin` of
   // OptixRenderer.cpp:71-93), 1 = along a Morton curve of the brick centres.  Cells are only ever found through their
@@ -292,8 +294,7 @@ struct ExaHipRenderer {
   static constexpr double kRopeActiveFraction = 0.4;
   bool ropeWanted() const
   {
-    // (the rope march reads the region's packed record from the leaf: scenes whose records do not pack keep the stack walk)
-    if (!useKd() || ropeFailed || walkMode == 1 || leafBeginBits == 0) return false;
+    if (!useKd() || ropeFailed || walkMode == 1) return false;
     if (walkMode == 2) return true;
     return double(activeRegions) >= kRopeActiveFraction * double(sc.numRegions);
   }
@@ -929,7 +930,7 @@ struct ExaHipRenderer {
     }
     a.kdNodes = kdNodes.p;
     // the instrumented counters re-check every leaf against its region record, so they walk the tree with region ids
-    const bool packed = kdMarchNodes.p != nullptr && !(stats && statsMode == 1);
+    const bool packed = packRecords && kdMarchNodes.p != nullptr && !(stats && statsMode == 1);
     a.kdMarchNodes = packed ? kdMarchNodes.p : kdNodes.p;
     a.kdMarchRoot = packed ? kdMarchRoot : kdRoot;
     // A tree that is one leaf (a one-region scene) has no node to carry the activity bits: the walks start at
@@ -1790,6 +1791,7 @@ int exa_hip_set_option(ExaHipRenderer *h, const char *key, int32_t value)
   }
   if (!std::strcmp(key, "interleave")) { h->interleave = value != 0; return 0; }
   if (!std::strcmp(key, "addr64")) { h->addr64 = value != 0; return 0; }
+  if (!std::strcmp(key, "pack_records")) { h->packRecords = value != 0; return 0; }
   if (!std::strcmp(key, "brick_order")) {
     if (value && !h->brickOrderPossible) {
       h->fail("exa_hip_set_option: brick_order 1 needs channel offsets f * totalCells and brick begins that partition [0, totalCells)");

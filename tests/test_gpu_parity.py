@@ -228,6 +228,21 @@ def test_ao_rays_match_up_to_trig_ulps():
 
 
 @pytest.mark.parametrize("accel", [1, 2], ids=["kd", "rope"])
+@pytest.mark.parametrize("name", ["amr_grad", "amr_2ch", "amr_iso", "ex4_grad", "amr_mesh_ao"])
+def test_region_records_that_do_not_pack_change_no_pixel(name, accel):
+    # option pack_records 0: the march takes region ids from the walk and loads the region records — what a scene does whose
+    # records {first brick, brick count, level} do not fit a 32-bit leaf reference (BASELINE-size scenes all pack; the exajet-like
+    # scene grown to 1.2e9 cells does not).  Same frame, same counters, with either walk.
+    case, frames = CASES[name](), 2
+    case.accel = accel
+    ref = case.run_hip(frames=frames, stats=True)
+    case.options = {"pack_records": 0}
+    got = case.run_hip(frames=frames, stats=True)
+    assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1].view(np.uint32), ref[1].view(np.uint32))
+    assert {k: got[2][k] for k in STAT_KEYS} == {k: ref[2][k] for k in STAT_KEYS}
+
+
+@pytest.mark.parametrize("accel", [1, 2], ids=["kd", "rope"])
 def test_ao_rays_beside_the_march_change_no_pixel(accel):
     # option ao_overlap: the AO launch in front of the march (0, the default) or on a side stream beside it, the pixels finished by
     # compositeKdKernel (1); deferred (ao_defer 1, default), sorted (2) or inline (0) rays: one frame, bit for bit, over 3 samples
