@@ -59,7 +59,9 @@ def check(seed):
     for key, val in (("brick_order", 1), ("interleave", 0), ("addr64", 1), ("prepass_split", 0), ("brick_order", 0), ("interleave", 1),
                      ("prepass_split", 1), ("addr64", 0), ("ao_defer", 0), ("ao_defer", 2), ("ao_defer", 1),
                      # round 5: which walk the march takes, and whether the AO rays run beside it
-                     ("walk", 1), ("walk", 2), ("ao_overlap", 0), ("walk", 0), ("ao_overlap", 1)):
+                     ("walk", 1), ("walk", 2), ("ao_overlap", 0), ("walk", 0), ("ao_overlap", 1),
+                     # ... and region ids instead of packed region records in the walk's leaf references, with either walk
+                     ("pack_records", 0), ("walk", 1), ("walk", 2), ("pack_records", 1), ("ao_overlap", 0), ("walk", 0)):
         R.setOption(key, val)
         for k in range(2 if key == "prepass_split" else 1):      # the plan changes after its measuring frame
             if not _same(_frames(R), base):
