@@ -2279,6 +2279,11 @@ __global__ __launch_bounds__(kKdBlock, marchWaves(MULTI, STATS, SMALL, NCH, ROPE
   constexpr int KS = MULTI == 1 ? kKdStackMultiEntries : kKdStackEntries;         // entries the walk keeps there
   // entries of the lane's segment queue: the rope walk keeps no stack and gives the queue that LDS as well
   constexpr int QN = ROPE ? (MULTI == 1 ? kRopeQueueMulti : kRopeQueue) : kSegQueue;
+  // the occupancy a variant is compiled for is only reached if that many workgroups' LDS fit a CU (160 KB): one TF table (one
+  // primary channel) + the lane's queue, and for the stack walk its stack
+  static_assert(MULTI != 0 || (size_t(EXA_NUM_XF_VALUES) * sizeof(float4) + size_t(kKdBlock) * (ROPE ? QN * 16 : (KSB + QN) * 12))
+                                  * marchWaves(MULTI, STATS, SMALL, NCH, ROPE) <= 160 * 1024,
+                "LDS per workgroup x waves per SIMD exceeds the CU's 160 KB: shorten the queue or lower the occupancy");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float4 *xfLds = reinterpret_cast<float4 *>(smem);
   unsigned char *sp0 = smem + size_t(a.numXfChannels) * EXA_NUM_XF_VALUES * sizeof(float4);
